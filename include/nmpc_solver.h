@@ -1,0 +1,154 @@
+/*
+ * nmpc_solver.h -- C ABI of the MI355X batched NMPC solver (libnmpc_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of wljungbergh/mpc-trajectory-generator that
+ * this project accelerates: the NMPC solve that the reference performs through OpEn's generated
+ * solver.  Reference interface each entry point replaces (paths relative to the reference repo):
+ *
+ *   nmpc_new / nmpc_free      og.tcp.OptimizerTcpManager(path).start() / .kill()
+ *                             src/path_generator.py:218-220,408,417 ; src/mpc/mpc_generator.py:220
+ *                             (and the offline code generation of src/mpc/mpc_generator.py:173-193:
+ *                             the quantities that build() bakes into the generated crate are the
+ *                             fields of nmpc_problem / nmpc_opts)
+ *   nmpc_ping                 mng.ping()                       src/path_generator.py:222
+ *   nmpc_solve_batch_host     mng.call(parameters)             src/mpc/mpc_generator.py:206
+ *   nmpc_solve_batch_device   same, operands already in HBM    (B parameter vectors per call)
+ *   nmpc_status fields        solution_data.exit_status / .solve_time_ms / ...
+ *                             src/mpc/mpc_generator.py:211-214
+ *   nmpc_eval_batch_*         the generated cost / grad / mapping_f1 / mapping_f2 C functions that
+ *                             build() emits (declared by src/mpc/mpc_generator.py:66-175)
+ *
+ * The shape follows OpEn's own generated C bindings (<name>_new / <name>_solve / <name>_free with a
+ * status struct), widened from one instance to a batch.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success
+ * or a negative nmpc_error, never throws; buffers are caller-allocated; a handle is not
+ * thread-safe, distinct handles are.  Data layout (all IEEE f64, row-major):
+ *   p  [B][n_p]   parameter vectors, layout of reference src/path_generator.py:378-379
+ *   u  [B][n_u]   decision vectors (v_0, w_0, v_1, w_1, ...)   src/mpc/mpc_generator.py:83,157-158
+ *   y  [B][n1]    ALM multipliers of F1 = [acc ; omega_acc]    src/mpc/mpc_generator.py:162
+ */
+#ifndef NMPC_SOLVER_H
+#define NMPC_SOLVER_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMPC_ABI_VERSION 1
+
+typedef enum nmpc_error {
+    NMPC_OK = 0,
+    NMPC_ERR_BAD_PROBLEM = -1,      /* unsupported dims / non-positive ts                     */
+    NMPC_ERR_BAD_OPTS = -2,
+    NMPC_ERR_BAD_ARG = -3,          /* NULL pointer, B < 0, B > max_batch                     */
+    NMPC_ERR_NO_DEVICE = -4,        /* no HIP device / wrong architecture                     */
+    NMPC_ERR_HIP = -5,              /* a HIP runtime call failed; see nmpc_last_error()       */
+    NMPC_ERR_DEAD_HANDLE = -6       /* handle was killed                                      */
+} nmpc_error;
+
+/* What the reference bakes into the generated solver at build() time
+ * (configs/default.yaml:6-13,18,34-40 ; src/mpc/mpc_generator.py:70-71,151-168). */
+typedef struct nmpc_problem {
+    int32_t N;        /* N_hor, 2..64                               */
+    int32_t nobs;     /* Nobs    : static circle slots, 0..64       */
+    int32_t ndyn;     /* Ndynobs : dynamic ellipse slots, 0..3      */
+    int32_t reserved;
+    double ts;
+    double vmin, vmax, wmax;     /* U = ([vmin,vmax] x [-wmax,wmax])^N      (:151-153) */
+    double amin, amax, awmax;    /* C = [amin,amax]^N x [-awmax,awmax]^N    (:164-168) */
+} nmpc_problem;
+
+/* OpEn solver configuration (src/mpc/mpc_generator.py:184-186; opengen defaults otherwise).
+ * Deviation: the reference stops on wall-clock (max_duration 0.5 s, :9,186); a batch must be
+ * deterministic, so only the iteration caps apply. */
+typedef struct nmpc_opts {
+    double tolerance;            /* 1e-4 */
+    double initial_tolerance;    /* 1e-4 */
+    double delta_tolerance;      /* 1e-4 */
+    double initial_penalty;      /* 1.0  */
+    double penalty_update;       /* 5.0  */
+    double tolerance_update;     /* 0.1  */
+    double sufficient_decrease;  /* 0.1  */
+    int32_t lbfgs_memory;        /* 10 (1..10) */
+    int32_t max_inner;           /* 500  */
+    int32_t max_outer;           /* 10   */
+    int32_t reserved;
+} nmpc_opts;
+
+typedef enum nmpc_exit {
+    NMPC_CONVERGED = 0,
+    NMPC_NOT_CONVERGED_ITERATIONS = 1,
+    NMPC_NOT_CONVERGED_OUT_OF_TIME = 2,      /* never produced (no wall-clock stop)          */
+    NMPC_NOT_CONVERGED_COST = 3,
+    NMPC_NOT_CONVERGED_NOT_FINITE = 4
+} nmpc_exit;
+
+/* One per instance: the fields of OpEn's solver status plus evaluation
+ * counters.  72 bytes. */
+typedef struct nmpc_status {
+    int32_t  exit_status;            /* nmpc_exit                                   */
+    uint32_t num_outer_iterations;
+    uint32_t num_inner_iterations;
+    uint32_t num_cost_evals;         /* forward-only evaluations of psi             */
+    uint32_t num_grad_evals;         /* forward + adjoint evaluations               */
+    uint32_t reserved;
+    double last_problem_norm_fpr;
+    double delta_y_norm_over_c;
+    double f2_norm;
+    double penalty;
+    double cost;
+    double solve_time_ms;            /* batch wall time / 1 (host path); 0 on the device path */
+} nmpc_status;
+
+typedef struct nmpc_handle nmpc_handle;
+
+void nmpc_default_opts(nmpc_opts *opts);
+int nmpc_n_u(const nmpc_problem *pb);
+int nmpc_n_p(const nmpc_problem *pb);
+int nmpc_n1(const nmpc_problem *pb);
+int nmpc_n2(const nmpc_problem *pb);
+
+/* Creates a solver for one problem shape on HIP device `device_id`, with room for `max_batch`
+ * instances.  opts == NULL selects nmpc_default_opts. */
+int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int max_batch,
+             nmpc_handle **out);
+void nmpc_free(nmpc_handle *h);
+int nmpc_ping(const nmpc_handle *h);
+const char *nmpc_last_error(const nmpc_handle *h);
+int nmpc_abi_version(void);
+
+/* Device path: every pointer is device memory on the handle's device; the launch is enqueued on
+ * `stream` (a hipStream_t, NULL = default stream) and the call returns without synchronising.
+ *   d_u      [B][n_u]  in: initial guess, out: solution
+ *   d_y0     [B][n1]   initial multipliers, or NULL (zeros)
+ *   d_c0     [B]       initial penalties, or NULL (opts.initial_penalty)
+ *   d_y_out  [B][n1]   final multipliers, or NULL
+ *   d_status [B]       or NULL                                                              */
+int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_u,
+                            const double *d_y0, const double *d_c0, double *d_y_out,
+                            nmpc_status *d_status, void *stream);
+
+/* Host path: same operands in host memory; copies in, solves, copies out, synchronises. */
+int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, const double *y0,
+                          const double *c0, double *y_out, nmpc_status *status);
+
+/* psi(u; c, y, p), grad_u psi, F1, F2 for B instances (c == NULL: zeros -> plain f; y == NULL: zeros).
+ * Outputs may be NULL.  psi [B], grad [B][n_u], F1 [B][n1], F2 [B][n2]. */
+int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const double *d_u,
+                           const double *d_c, const double *d_y, double *d_psi, double *d_grad,
+                           double *d_F1, double *d_F2, void *stream);
+int nmpc_eval_batch_host(nmpc_handle *h, int B, const double *p, const double *u, const double *c,
+                         const double *y, double *psi, double *grad, double *F1, double *F2);
+
+/* Arithmetic primitives of the kernels, exported for bit-level checks: out_s/out_c [n]. */
+int nmpc_test_sincos_host(nmpc_handle *h, int n, const double *x, double *out_s, double *out_c);
+/* a/b and sqrt(a) as the device computes them: out_div/out_sqrt [n]. */
+int nmpc_test_divsqrt_host(nmpc_handle *h, int n, const double *a, const double *b,
+                           double *out_div, double *out_sqrt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of libnmpc_hip.so (the C ABI of include/nmpc_solver.h).
+
+There is no CPU fallback: if the HIP library is missing it is built with hipcc, and if that is
+impossible or no MI355X is visible the constructor of the solver raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libnmpc_hip.so")
+
+# every symbol include/nmpc_solver.h declares
+SYMBOLS = (
+    "nmpc_default_opts", "nmpc_n_u", "nmpc_n_p", "nmpc_n1", "nmpc_n2", "nmpc_new", "nmpc_free",
+    "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_solve_batch_device",
+    "nmpc_solve_batch_host", "nmpc_eval_batch_device", "nmpc_eval_batch_host",
+    "nmpc_test_sincos_host", "nmpc_test_divsqrt_host",
+)
+
+ERRORS = {0: "ok", -1: "bad problem", -2: "bad opts", -3: "bad argument", -4: "no HIP device",
+          -5: "HIP runtime error", -6: "dead handle"}
+
+EXIT_STATUS = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotConvergedCost",
+               "NotConvergedNotFiniteComputation")
+
+
+class NmpcProblem(C.Structure):
+    _fields_ = [("N", C.c_int32), ("nobs", C.c_int32), ("ndyn", C.c_int32), ("reserved", C.c_int32),
+                ("ts", C.c_double), ("vmin", C.c_double), ("vmax", C.c_double), ("wmax", C.c_double),
+                ("amin", C.c_double), ("amax", C.c_double), ("awmax", C.c_double)]
+
+
+class NmpcOpts(C.Structure):
+    _fields_ = [("tolerance", C.c_double), ("initial_tolerance", C.c_double),
+                ("delta_tolerance", C.c_double), ("initial_penalty", C.c_double),
+                ("penalty_update", C.c_double), ("tolerance_update", C.c_double),
+                ("sufficient_decrease", C.c_double), ("lbfgs_memory", C.c_int32),
+                ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("reserved", C.c_int32)]
+
+
+STATUS_DTYPE = np.dtype([("exit_status", "<i4"), ("num_outer_iterations", "<u4"),
+                         ("num_inner_iterations", "<u4"), ("num_cost_evals", "<u4"),
+                         ("num_grad_evals", "<u4"), ("reserved", "<u4"),
+                         ("last_problem_norm_fpr", "<f8"), ("delta_y_norm_over_c", "<f8"),
+                         ("f2_norm", "<f8"), ("penalty", "<f8"), ("cost", "<f8"),
+                         ("solve_time_ms", "<f8")])
+assert STATUS_DTYPE.itemsize == 72
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 the kernels in-tree (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("nmpc_kernels.hip", "nmpc_device.h", "Makefile")]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "nmpc_solver.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        r = subprocess.run(["make", "-C", _CSRC, "-B", "libnmpc_hip.so"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("building libnmpc_hip.so failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load (building if needed) the HIP library; raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = build_library()
+    lib = C.CDLL(path)
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    lib.nmpc_default_opts.argtypes = [C.POINTER(NmpcOpts)]
+    lib.nmpc_default_opts.restype = None
+    for f in ("nmpc_n_u", "nmpc_n_p", "nmpc_n1", "nmpc_n2"):
+        getattr(lib, f).argtypes = [C.POINTER(NmpcProblem)]
+        getattr(lib, f).restype = C.c_int
+    lib.nmpc_new.argtypes = [C.POINTER(NmpcProblem), C.POINTER(NmpcOpts), C.c_int, C.c_int, C.POINTER(vp)]
+    lib.nmpc_free.argtypes = [vp]
+    lib.nmpc_free.restype = None
+    lib.nmpc_ping.argtypes = [vp]
+    lib.nmpc_last_error.argtypes = [vp]
+    lib.nmpc_last_error.restype = C.c_char_p
+    lib.nmpc_abi_version.restype = C.c_int
+    lib.nmpc_solve_batch_device.argtypes = [vp, C.c_int] + [vp] * 7
+    lib.nmpc_solve_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, vp]
+    lib.nmpc_eval_batch_device.argtypes = [vp, C.c_int] + [vp] * 9
+    lib.nmpc_eval_batch_host.argtypes = [vp, C.c_int] + [dp] * 8
+    lib.nmpc_test_sincos_host.argtypes = [vp, C.c_int, dp, dp, dp]
+    lib.nmpc_test_divsqrt_host.argtypes = [vp, C.c_int, dp, dp, dp, dp]
+    _lib = lib
+    return lib
+
+
+def as_dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None

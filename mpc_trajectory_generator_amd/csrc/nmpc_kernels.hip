@@ -1,0 +1,957 @@
+// nmpc_kernels.hip -- batched NMPC solve on MI355X (gfx950): PANOC inner iteration + L-BFGS +
+// ALM/penalty outer loop, with the diff-drive rollout, stage/terminal costs, cross-track error and
+// circle/ellipse soft-constraint penalties evaluated per step, entirely on device in f64.
+//
+// What is restated (paths relative to the reference repo):
+//   cost / constraints   src/mpc/mpc_generator.py:66-171           (eval_psi)
+//   solver               OpEn's PANOC + ALM that src/mpc/mpc_generator.py:173-193 generates and
+//                        :206 calls; algorithm per SURVEY.md Appendix C  (solve kernel state machine)
+// This file is original CDNA4 code; nothing here is translated from OpEn's Rust or CasADi's C.
+#include "nmpc_device.h"
+#include "../../include/nmpc_solver.h"
+
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace nmpc {
+
+constexpr int NZ = 20;         // reference configs/default.yaml:35
+constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
+constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
+
+// PANOC constants
+constexpr double GAMMA_L_COEFF = 0.95;
+constexpr double DELTA_LIPSCHITZ = 1e-12;
+constexpr double EPSILON_LIPSCHITZ = 1e-6;
+constexpr double LIPSCHITZ_UPDATE_EPSILON = 1e-6;
+constexpr int MAX_LIPSCHITZ_UPDATE_ITERATIONS = 10;
+constexpr double MAX_LIPSCHITZ_CONSTANT = 1e9;
+constexpr double MIN_LIPSCHITZ_CONSTANT = 1e-10;
+constexpr int MAX_LINESEARCH_ITERATIONS = 10;
+constexpr double LBFGS_SY_EPSILON = 1e-10;
+constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
+
+// LDS slice of one group (offsets in doubles)
+struct LdsMap {
+    int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
+    int seg;     // 5 per reference segment: s1x s1y dx dy inv
+    int obs;     // 3 per static circle: xs ys r^2
+    int f2;      // n2 penalty values
+    int rho;     // m
+    int S, Y;    // m slots x N lanes x (v, w)
+    int total;
+};
+
+struct KArgs {
+    nmpc_problem pb;
+    nmpc_opts op;
+    LdsMap map;
+    int B;
+    int n_p, n_u, n1, n2;
+    const double *p;
+    double *u;
+    const double *y0;
+    const double *c0;
+    double *y_out;
+    nmpc_status *st;
+    unsigned int *queue;
+    // eval kernel only
+    const double *ev_c;
+    const double *ev_y;
+    double *ev_psi, *ev_grad, *ev_F1, *ev_F2;
+};
+
+enum { SC_X0 = 0, SC_Y0, SC_TH0, SC_VINIT, SC_WINIT, SC_XF, SC_YF, SC_THF,
+       SC_Q, SC_QV, SC_QTH, SC_RV, SC_RW, SC_QN, SC_QTHN, SC_QCTE, SC_PA, SC_PW };
+
+#define NMPC_WAVE_SYNC()                                           \
+    do {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
+        __builtin_amdgcn_wave_barrier();                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
+    } while (0)
+
+// per-stage data of the dynamic ellipses, held in registers by the stage's lane
+struct DynStage {
+    double ex[NDYN_MAX], ey[NDYN_MAX], ca[NDYN_MAX], sa[NDYN_MAX], irx2[NDYN_MAX], iry2[NDYN_MAX];
+};
+
+// ---------------------------------------------------------------------------------------------
+// instance set-up: p -> LDS slice + per-lane registers     (reference mpc_generator.py:73-79,93-104,127-136)
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, const double *p, int t,
+                                                 double &vref, DynStage &dyn)
+{
+    const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
+    if (t < 8) L[a.map.sc + t] = p[t];                      // state, last input, target (p[8:10] unused)
+    if (t >= 8 && t < 18) L[a.map.sc + t] = p[t + 2];       // ten weights p[10:20]
+    vref = t < N ? p[NZ + t] : 0.0;
+    const double *ps = p + NZ + N;
+    for (int k = t; k < nobs; k += P) {
+        const double r = ps[3 * k + 2];
+        L[a.map.obs + 3 * k] = ps[3 * k];
+        L[a.map.obs + 3 * k + 1] = ps[3 * k + 1];
+        L[a.map.obs + 3 * k + 2] = r * r;
+    }
+    const double *pd = ps + 3 * nobs;
+#pragma unroll
+    for (int k = 0; k < NDYN_MAX; ++k) {
+        dyn.ex[k] = dyn.ey[k] = dyn.ca[k] = dyn.sa[k] = 0.0;
+        dyn.irx2[k] = dyn.iry2[k] = 1.0;
+        if (k < ndyn && t < N) {
+            const double *e = pd + (k * N + t) * 5;
+            dyn.ex[k] = e[0];
+            dyn.ey[k] = e[1];
+            dyn.irx2[k] = 1.0 / (e[2] * e[2]);
+            dyn.iry2[k] = 1.0 / (e[3] * e[3]);
+            sincos_cw(e[4], dyn.sa[k], dyn.ca[k]);
+        }
+    }
+    const double *pr = pd + 5 * ndyn * N;
+    if (t < N - 1) {
+        const double ax = pr[3 * t], ay = pr[3 * t + 1];
+        const double bx = pr[3 * t + 3], by = pr[3 * t + 4];
+        const double dx = bx - ax, dy = by - ay;
+        double *sg = L + a.map.seg + 5 * t;
+        sg[0] = ax;
+        sg[1] = ay;
+        sg[2] = dx;
+        sg[3] = dy;
+        sg[4] = 1.0 / (fma(dx, dx, dy * dy) + 1e-16);
+    }
+    NMPC_WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------
+// psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); F2_k left in the LDS slice
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, int t, double zv, double zw,
+                                         double c, double yv, double yw, double vref, const DynStage &dyn,
+                                         bool want_grad, double &psi, double &pen_out, double &gv,
+                                         double &gw, double &av_out, double &aw_out)
+{
+    const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
+    const double ts = a.pb.ts, inv_ts = 1.0 / a.pb.ts;
+    const bool in = t < N;
+    const double *sc = L + a.map.sc;
+    const double x0 = sc[SC_X0], y0 = sc[SC_Y0], th0 = sc[SC_TH0];
+    const double xf = sc[SC_XF], yf = sc[SC_YF], thf = sc[SC_THF];
+
+    // rollout (:88-90) as three prefix sums
+    const double thn = fma(ts, group_prefix<P>(zw, lane), th0);
+    const double th = from_prev<P>(thn, lane, th0);
+    double sn, cs;
+    sincos_cw(th, sn, cs);
+    const double xn = fma(ts, group_prefix<P>(zv * cs, lane), x0);
+    const double yn = fma(ts, group_prefix<P>(zv * sn, lane), y0);
+    const double xp = from_prev<P>(xn, lane, x0);
+    const double yp = from_prev<P>(yn, lane, y0);
+
+    const double cbar_inv = 1.0 / fmax(c, 1.0);
+    const double half_c = 0.5 * c;
+
+    double acc = (sc[SC_RV] * zv) * zv;                                           // (:84)
+    acc = fma(sc[SC_RW] * zw, zw, acc);
+    const double dv = zv - vref;                                                  // (:85)
+    acc = fma(sc[SC_QV] * dv, dv, acc);
+    {
+        const double ddx = xp - xf, ddy = yp - yf, dth = th - thf;                // (:86, 59-64)
+        acc = fma(sc[SC_Q], fma(ddx, ddx, ddy * ddy), acc);
+        acc = fma(sc[SC_QTH] * dth, dth, acc);
+    }
+    // cross-track error: min over the N-1 reference segments (:121-144)
+    double best = __builtin_inf();
+    int bi = 0;
+    {
+        const double *sg = L + a.map.seg;
+        for (int i = 0; i < N - 1; ++i, sg += 5) {
+            const double px = xn - sg[0], py = yn - sg[1];
+            const double dot = fma(px, sg[2], py * sg[3]);
+            const double that = dot * sg[4];
+            const double tst = fmin(fmax(that, 0.0), 1.0);
+            const double ex = fma(tst, sg[2], -px), ey = fma(tst, sg[3], -py);
+            const double d2 = fma(ex, ex, ey * ey);
+            if (d2 < best) { best = d2; bi = i; }
+        }
+    }
+    acc = fma(sc[SC_QCTE], best, acc);                                            // (:144)
+    // accelerations (:160-161), their cost (:170-171) and the ALM term
+    const double vprev = from_prev<P>(zv, lane, sc[SC_VINIT]);
+    const double wprev = from_prev<P>(zw, lane, sc[SC_WINIT]);
+    double av = (zv - vprev) * inv_ts, aw = (zw - wprev) * inv_ts;
+    acc = fma(sc[SC_PA] * av, av, acc);
+    acc = fma(sc[SC_PW] * aw, aw, acc);
+    const double tv = fma(yv, cbar_inv, av), tw = fma(yw, cbar_inv, aw);
+    double sv = tv - clampd(tv, a.pb.amin, a.pb.amax);
+    double sw = tw - clampd(tw, -a.pb.awmax, a.pb.awmax);
+    acc = fma(half_c, fma(sv, sv, sw * sw), acc);
+    if (t == N - 1) {                                                             // terminal (:148)
+        const double tx = xn - xf, ty = yn - yf, tth = thn - thf;
+        acc = fma(sc[SC_QN], fma(tx, tx, ty * ty), acc);
+        acc = fma(sc[SC_QTHN] * tth, tth, acc);
+    }
+    if (!in) { acc = 0.0; av = aw = sv = sw = 0.0; }
+    av_out = av;
+    aw_out = aw;
+    const double fsum = group_sum<P>(acc, lane);
+
+    // obstacle penalties on the post-update state (:106-119)
+    double pen = 0.0;
+    {
+        const double *ob = L + a.map.obs;
+        for (int k = 0; k < nobs; ++k, ob += 3) {
+            const double dx = xn - ob[0], dy = yn - ob[1];
+            const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));                   // (:112)
+            const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
+            if (t == 0) L[a.map.f2 + k] = f2;
+            pen = fma(f2, f2, pen);
+        }
+#pragma unroll
+        for (int k = 0; k < NDYN_MAX; ++k) {
+            if (k < ndyn) {
+                const double dx = xn - dyn.ex[k], dy = yn - dyn.ey[k];
+                const double ea = fma(dx, dyn.ca[k], dy * dyn.sa[k]);
+                const double eb = fma(dx, dyn.sa[k], -(dy * dyn.ca[k]));
+                const double h = fma(-(eb * eb), dyn.iry2[k], fma(-(ea * ea), dyn.irx2[k], 1.0));   // (:118)
+                const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
+                if (t == 0) L[a.map.f2 + nobs + k] = f2;
+                pen = fma(f2, f2, pen);
+            }
+        }
+    }
+    psi = fma(half_c, pen, fsum);
+    pen_out = pen;
+    if (!want_grad) return;
+    NMPC_WAVE_SYNC();          // F2_k written by lane 0 of the group are read by all its lanes below
+
+    // ---- adjoint sweep (what CasADi reverse AD generated for the reference) ----
+    double gx, gy;
+    {
+        const double *sg = L + a.map.seg + 5 * bi;          // arg-min segment of this stage
+        const double px = xn - sg[0], py = yn - sg[1];
+        const double dot = fma(px, sg[2], py * sg[3]);
+        const double that = dot * sg[4];
+        const double tst = fmin(fmax(that, 0.0), 1.0);
+        const double ex = fma(tst, sg[2], -px), ey = fma(tst, sg[3], -py);
+        const double ed = fma(ex, sg[2], ey * sg[3]);
+        const double m = (that > 0.0 && that < 1.0) ? ed * sg[4] : 0.0;
+        const double two_q = 2.0 * sc[SC_QCTE];
+        gx = two_q * fma(m, sg[2], -ex);
+        gy = two_q * fma(m, sg[3], -ey);
+    }
+    {
+        const double *ob = L + a.map.obs;
+        const double *f2 = L + a.map.f2;
+        for (int k = 0; k < nobs; ++k, ob += 3) {
+            const double wk = -2.0 * (c * f2[k]);
+            const double dx = xn - ob[0], dy = yn - ob[1];
+            const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));
+            if (h > 0.0) { gx = fma(wk, dx, gx); gy = fma(wk, dy, gy); }
+        }
+#pragma unroll
+        for (int k = 0; k < NDYN_MAX; ++k) {
+            if (k < ndyn) {
+                const double wk = -2.0 * (c * f2[nobs + k]);
+                const double dx = xn - dyn.ex[k], dy = yn - dyn.ey[k];
+                const double ea = fma(dx, dyn.ca[k], dy * dyn.sa[k]);
+                const double eb = fma(dx, dyn.sa[k], -(dy * dyn.ca[k]));
+                const double h = fma(-(eb * eb), dyn.iry2[k], fma(-(ea * ea), dyn.irx2[k], 1.0));
+                if (h > 0.0) {
+                    const double A = ea * dyn.irx2[k], Bq = eb * dyn.iry2[k];
+                    const double hx = fma(A, dyn.ca[k], Bq * dyn.sa[k]);
+                    const double hy = fma(A, dyn.sa[k], -(Bq * dyn.ca[k]));
+                    gx = fma(wk, hx, gx);
+                    gy = fma(wk, hy, gy);
+                }
+            }
+        }
+    }
+    // the post-update state of stage t is the tracked state of stage t+1 (:86) or the terminal state (:148)
+    const double wq = t < N - 1 ? sc[SC_Q] : sc[SC_QN];
+    const double wth = t < N - 1 ? sc[SC_QTH] : sc[SC_QTHN];
+    gx = fma(2.0 * wq, xn - xf, gx);
+    gy = fma(2.0 * wq, yn - yf, gy);
+    double gt = (2.0 * wth) * (thn - thf);
+    double qa = fma(c, sv, (2.0 * sc[SC_PA]) * av);
+    double qw = fma(c, sw, (2.0 * sc[SC_PW]) * aw);
+    if (!in) { gx = gy = gt = qa = qw = 0.0; }
+    const double Sx = group_suffix<P>(gx, lane);
+    const double Sy = group_suffix<P>(gy, lane);
+    const double e = fma(Sy, cs, -(Sx * sn));
+    const double Dt = in ? (ts * zv) * e : 0.0;
+    const double St = group_suffix<P>(in ? gt + from_next<P>(Dt, lane) : 0.0, lane);
+    const double qan = from_next<P>(qa, lane), qwn = from_next<P>(qw, lane);
+    const double dynv = fma(Sx, cs, Sy * sn);
+    double g1 = fma(2.0 * sc[SC_RV], zv, (2.0 * sc[SC_QV]) * dv);
+    g1 = fma(inv_ts, qa - qan, g1);
+    g1 = fma(ts, dynv, g1);
+    double g2 = (2.0 * sc[SC_RW]) * zw;
+    g2 = fma(inv_ts, qw - qwn, g2);
+    g2 = fma(ts, St, g2);
+    gv = in ? g1 : 0.0;
+    gw = in ? g2 : 0.0;
+}
+
+// dot product of two horizon vectors (lane t holds the (v_t, w_t) pair)
+template <int P>
+__device__ __forceinline__ double hdot(double av, double aw, double bv, double bw, int lane)
+{
+    return group_sum<P>(fma(av, bv, aw * bw), lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cost-layer kernel: one evaluation per instance (parity tests, F1/F2 mapping API)
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
+{
+    extern __shared__ double lds[];
+    constexpr int K = 64 / P;
+    const int lane = threadIdx.x, g = lane / P, t = lane % P;
+    double *L = lds + g * a.map.total;
+    const int N = a.pb.N;
+    const int inst = blockIdx.x * K + g;
+    const int b = inst < a.B ? inst : a.B - 1;          // surplus groups redo the last instance, write nothing
+    double vref;
+    DynStage dyn;
+    prepare_instance<P>(a, L, a.p + (size_t)b * a.n_p, t, vref, dyn);
+    const double *u = a.u + (size_t)b * a.n_u;
+    const double zv = t < N ? u[2 * t] : 0.0, zw = t < N ? u[2 * t + 1] : 0.0;
+    const double c = a.ev_c ? a.ev_c[b] : 0.0;
+    const double yv = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + t] : 0.0;
+    const double yw = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + N + t] : 0.0;
+    double psi, pen, gv, gw, av, aw;
+    eval_psi<P>(a, L, lane, t, zv, zw, c, yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
+    if (inst >= a.B) return;
+    if (t == 0 && a.ev_psi) a.ev_psi[b] = psi;
+    if (t < N) {
+        if (a.ev_grad) { a.ev_grad[(size_t)b * a.n_u + 2 * t] = gv; a.ev_grad[(size_t)b * a.n_u + 2 * t + 1] = gw; }
+        if (a.ev_F1) { a.ev_F1[(size_t)b * a.n1 + t] = av; a.ev_F1[(size_t)b * a.n1 + N + t] = aw; }
+    }
+    if (a.ev_F2) for (int k = t; k < a.n2; k += P) a.ev_F2[(size_t)b * a.n2 + k] = L[a.map.f2 + k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// the solver: per-group state machine, one psi evaluation per pass
+// ---------------------------------------------------------------------------------------------
+enum : int { ST_IDLE = 0, ST_INIT0, ST_INIT1, ST_LIP, ST_FB0, ST_LS, ST_ALM };
+
+template <int P>
+__global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, g = lane / P, t = lane % P;
+    const int gbase = g * P;
+    double *L = lds + g * a.map.total;
+    const int N = a.pb.N, m = a.op.lbfgs_memory;
+    const bool in = t < N;
+    double2 *LS = reinterpret_cast<double2 *>(L + a.map.S);
+    double2 *LY = reinterpret_cast<double2 *>(L + a.map.Y);
+    double *Lrho = L + a.map.rho;
+
+    // ---- per-group state (every lane of a group holds the same control values) ----
+    int state = ST_IDLE, inst = -1;
+    bool done = false;                       // queue exhausted for this group
+    double vref = 0.0;
+    DynStage dyn;
+#pragma unroll
+    for (int k = 0; k < NDYN_MAX; ++k) { dyn.ex[k] = dyn.ey[k] = dyn.ca[k] = dyn.sa[k] = 0.0; dyn.irx2[k] = dyn.iry2[k] = 1.0; }
+    // horizon vectors: (v, w) pair per lane
+    double uv = 0, uw = 0, gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0;   // u, grad, grad-step, half-step, gamma*fpr
+    double dv = 0, dw = 0, pv = 0, pw = 0, qv = 0, qw = 0;                                      // direction, u_plus, previous gradient
+    double osv = 0, osw = 0, ogv = 0, ogw = 0;                                                  // L-BFGS old state / old gamma*fpr
+    double yv = 0, yw = 0, ypv = 0, ypw = 0;                                                    // multipliers y, y_plus
+    double zv = 0, zw = 0;                                                                      // query point of the next evaluation
+    bool need_grad = false;
+    // PANOC scalars
+    double cost = 0, Lc = 0, gamma = 0, sigma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0, norm_h = 0, H0 = 1;
+    int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
+    bool lb_first = true;
+    unsigned num_iter = 0;
+    // ALM scalars
+    double pen_c = 1, eps_nu = 0, dy_norm = 0, f2_norm = 0, dy_norm_plus = 0, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
+    int nu = 0, inner_status = 0;
+    unsigned inner_total = 0, n_cost = 0, n_grad = 0;
+
+    for (;;) {
+        // ------------------------------------------------------------------ fetch work
+        if (state == ST_IDLE && !done) {
+            unsigned nxt = 0;
+            if (t == 0) nxt = atomicAdd(a.queue, 1u);
+            nxt = (unsigned)lane_get_i((int)nxt, gbase);
+            if (nxt >= (unsigned)a.B) {
+                done = true;
+            } else {
+                inst = (int)nxt;
+                prepare_instance<P>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+                const double *u0 = a.u + (size_t)inst * a.n_u;
+                uv = in ? u0[2 * t] : 0.0;
+                uw = in ? u0[2 * t + 1] : 0.0;
+                yv = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + t] : 0.0;
+                yw = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + N + t] : 0.0;
+                ypv = yv; ypw = yw;
+                const double c0 = a.c0 ? a.c0[inst] : 0.0;
+                pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
+                eps_nu = a.op.initial_tolerance;
+                dy_norm = f2_norm = f2_norm_plus = 0.0;
+                dy_norm_plus = DBL_MAX;
+                nu = 0; inner_total = 0; n_cost = 0; n_grad = 0; inner_status = 0;
+                qv = qw = 0.0;                       // gradient_u_previous starts at zero for every solve
+                // outer iteration 0: y <- Pi_Y(y), start PANOC
+                yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);
+                lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                zv = uv; zw = uw; need_grad = true; state = ST_INIT0;
+            }
+        }
+        const bool live = state != ST_IDLE;
+        if (!__any(live)) break;
+
+        // ------------------------------------------------------------------ one evaluation of psi per group
+        double psi, pen, egv = 0, egw = 0, eav, eaw;
+        const bool wg = __any(live && need_grad);
+        eval_psi<P>(a, L, lane, t, zv, zw, pen_c, yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
+        if (!live) continue;
+
+        // ------------------------------------------------------------------ consume it
+        bool begin_step = false;      // (u, cost, g, grad-step, half-step) consistent: start the next PANOC step
+        bool end_iter = false;        // an iteration finished: count it, then begin_step
+        bool inner_done = false;
+        bool start_panoc = false;
+        bool finished = false;
+        int final_status = 0;
+
+        if (state == ST_INIT0) {
+            n_grad++;
+            cost = psi; gv = egv; gw = egw;
+            // local Lipschitz estimate: perturb u by h_i = max(1e-6 u_i, 1e-12)
+            const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
+            const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
+            norm_h = sqrt(group_sum<P>(in ? fma(h1, h1, h2 * h2) : 0.0, lane));
+            zv = in ? uv + h1 : 0.0;
+            zw = in ? uw + h2 : 0.0;
+            need_grad = true;
+            state = ST_INIT1;
+        } else if (state == ST_INIT1) {
+            n_grad++;
+            const double d1 = egv - gv, d2 = egw - gw;
+            Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / norm_h;
+            gamma = GAMMA_L_COEFF / fmax(Lc, MIN_LIPSCHITZ_CONSTANT);
+            sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+            sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
+            hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
+            hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
+            begin_step = true;
+        } else if (state == ST_LIP) {
+            n_cost++;
+            const double cost_uh = psi;
+            const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
+                             + (GAMMA_L_COEFF / (2.0 * gamma)) * nr2;
+            if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && Lc < MAX_LIPSCHITZ_CONSTANT && cost_uh > rhs) {
+                lb_active = 0; lb_first = true;                   // L-BFGS buffer invalidated
+                Lc *= 2.0;
+                gamma /= 2.0;
+                sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
+                hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
+                hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
+                rv = uv - hv; rw = uw - hw;
+                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                norm_r = sqrt(nr2);
+                lip_it++;
+                zv = hv; zw = hw; need_grad = false;              // stay in ST_LIP
+            } else {
+                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                // ---- L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
+                if (lb_first) {
+                    lb_first = false;
+                    osv = uv; osw = uw; ogv = rv; ogw = rw;
+                } else {
+                    const double s1 = uv - osv, s2 = uw - osw, y1 = rv - ogv, y2 = rw - ogw;
+                    const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
+                    bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
+                    if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
+                    if (ok) {
+                        osv = uv; osw = uw; ogv = rv; ogw = rw;
+                        lb_head = lb_head == 0 ? m - 1 : lb_head - 1;
+                        if (in) { LS[lb_head * N + t] = make_double2(s1, s2); LY[lb_head * N + t] = make_double2(y1, y2); }
+                        if (t == 0) Lrho[lb_head] = 1.0 / ys;
+                        H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
+                        if (lb_active < m) lb_active++;
+                        NMPC_WAVE_SYNC();
+                    }
+                }
+                if (iteration == 0) {
+                    // first iteration: plain forward-backward step, no line search
+                    uv = hv; uw = hw;
+                    zv = uv; zw = uw; need_grad = true;
+                    state = ST_FB0;
+                } else {
+                    // ---- direction d = H r by the two-loop recursion ----
+                    dv = rv; dw = rw;
+                    double alpha[MAXMEM];
+#pragma unroll
+                    for (int k = 0; k < MAXMEM; ++k) {
+                        alpha[k] = 0.0;
+                        if (k < lb_active) {
+                            int slot = lb_head + k; if (slot >= m) slot -= m;
+                            const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
+                            const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
+                            const double al = Lrho[slot] * hdot<P>(s.x, s.y, dv, dw, lane);
+                            alpha[k] = al;
+                            dv = fma(-al, y.x, dv); dw = fma(-al, y.y, dw);
+                        }
+                    }
+                    if (lb_active > 0) { dv = H0 * dv; dw = H0 * dw; }
+#pragma unroll
+                    for (int k = MAXMEM - 1; k >= 0; --k) {
+                        if (k < lb_active) {
+                            int slot = lb_head + k; if (slot >= m) slot -= m;
+                            const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
+                            const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
+                            const double be = Lrho[slot] * hdot<P>(y.x, y.y, dv, dw, lane);
+                            const double ab = alpha[k] - be;
+                            dv = fma(ab, s.x, dv); dw = fma(ab, s.y, dw);
+                        }
+                    }
+                    // ---- line search set-up: rhs = FBE(u) - sigma ||r||^2 ----
+                    const double e1 = sv_ - hv, e2 = sw_ - hw;
+                    const double dist2 = group_sum<P>(fma(e1, e1, e2 * e2), lane);
+                    const double gg = hdot<P>(gv, gw, gv, gw, lane);
+                    const double fbe = cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
+                    rhs_ls = fbe - sigma * nr2;
+                    tau = 1.0; ls_n = 0;
+                    const double omt = 1.0 - tau;
+                    pv = fma(-tau, dv, fma(-omt, rv, uv));
+                    pw = fma(-tau, dw, fma(-omt, rw, uw));
+                    qv = gv; qw = gw;                              // cache_previous_gradient
+                    zv = pv; zw = pw; need_grad = true;
+                    state = ST_LS;
+                }
+            }
+        } else if (state == ST_FB0) {
+            n_grad++;
+            cost = psi; gv = egv; gw = egw;
+            sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
+            hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
+            hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
+            end_iter = true;
+        } else if (state == ST_LS) {
+            n_grad++;
+            cost = psi; gv = egv; gw = egw;
+            sv_ = fma(-gamma, gv, pv); sw_ = fma(-gamma, gw, pw);
+            hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
+            hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
+            const double e1 = sv_ - hv, e2 = sw_ - hw;
+            const double dist2 = group_sum<P>(fma(e1, e1, e2 * e2), lane);
+            const double gg = hdot<P>(gv, gw, gv, gw, lane);
+            const double lhs = cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
+            if (lhs > rhs_ls && ls_n < MAX_LINESEARCH_ITERATIONS) {
+                tau /= 2.0; ls_n++;
+                const double omt = 1.0 - tau;
+                pv = fma(-tau, dv, fma(-omt, rv, uv));
+                pw = fma(-tau, dw, fma(-omt, rw, uw));
+                qv = gv; qw = gw;
+                zv = pv; zw = pw; need_grad = true;                // stay in ST_LS
+            } else {
+                uv = pv; uw = pw;
+                end_iter = true;
+            }
+        } else if (state == ST_ALM) {
+            n_cost++;
+            // y+ = y + c (F1 - Pi_C(F1 + y / max(c,1))), ||y+ - y||, ||F2||
+            const double cbar_inv = 1.0 / fmax(pen_c, 1.0);
+            const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
+            ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
+            ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+            const double d1 = ypv - yv, d2 = ypw - yw;
+            dy_norm_plus = sqrt(group_sum<P>(in ? fma(d1, d1, d2 * d2) : 0.0, lane));
+            f2_norm_plus = sqrt(pen);
+            const double SMALL = DBL_EPSILON;
+            const bool crit1 = nu > 0 && dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL;
+            const bool crit2 = a.n2 == 0 || f2_norm_plus <= a.op.delta_tolerance + SMALL;
+            const bool crit3 = eps_nu <= a.op.tolerance + SMALL;
+            if (crit1 && crit2 && crit3) {
+                finished = true; final_status = inner_status;
+            } else {
+                const bool stall = nu == 0 || (dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
+                                               f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
+                if (!stall) pen_c *= a.op.penalty_update;
+                eps_nu = fmax(a.op.tolerance_update * eps_nu, a.op.tolerance);
+                yv = ypv; yw = ypw;
+                dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
+                nu++;
+                if (nu == a.op.max_outer) { finished = true; final_status = NMPC_NOT_CONVERGED_ITERATIONS; }
+                else start_panoc = true;
+            }
+        }
+
+        if (end_iter) {
+            iteration++;
+            // OpEn: while step() && num_iter < max_iter { num_iter++ }
+            if (!(num_iter < (unsigned)a.op.max_inner)) inner_done = true;
+            else { num_iter++; begin_step = true; }
+        }
+        if (begin_step) {
+            rv = uv - hv; rw = uw - hw;
+            nr2 = hdot<P>(rv, rw, rv, rw, lane);
+            norm_r = sqrt(nr2);
+            bool exit_now = false;
+            if (norm_r < a.op.tolerance) {                         // fpr test, then the AKKT test
+                const double a1 = rv / gamma + (gv - qv), a2 = rw / gamma + (gw - qw);
+                exit_now = sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu;
+            }
+            if (exit_now) inner_done = true;
+            else { lip_it = 0; zv = hv; zw = hw; need_grad = false; state = ST_LIP; }
+        }
+        if (inner_done) {
+            inner_status = num_iter < (unsigned)a.op.max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
+            inner_total += num_iter;
+            last_fpr = norm_r; last_cost = cost;
+            uv = hv; uw = hw;                                      // PANOC returns the feasible half step
+            const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
+            if (group_sum<P>((in && !fin) ? 1.0 : 0.0, lane) > 0.0) {
+                finished = true; final_status = NMPC_NOT_CONVERGED_NOT_FINITE;
+            } else {
+                zv = uv; zw = uw; need_grad = false; state = ST_ALM;
+            }
+        }
+        if (start_panoc) {
+            yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);
+            lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+            zv = uv; zw = uw; need_grad = true; state = ST_INIT0;
+        }
+        if (finished) {
+            if (in) {
+                double *uo = a.u + (size_t)inst * a.n_u;
+                uo[2 * t] = uv; uo[2 * t + 1] = uw;
+                if (a.y_out) { a.y_out[(size_t)inst * a.n1 + t] = ypv; a.y_out[(size_t)inst * a.n1 + N + t] = ypw; }
+            }
+            if (t == 0 && a.st) {
+                nmpc_status s;
+                s.exit_status = final_status;
+                s.num_outer_iterations = (uint32_t)(final_status == NMPC_NOT_CONVERGED_NOT_FINITE ? nu + 1 : (nu < a.op.max_outer ? nu + 1 : nu));
+                s.num_inner_iterations = inner_total;
+                s.num_cost_evals = n_cost;
+                s.num_grad_evals = n_grad;
+                s.reserved = 0;
+                s.last_problem_norm_fpr = last_fpr;
+                s.delta_y_norm_over_c = dy_norm_plus / pen_c;
+                s.f2_norm = f2_norm_plus;
+                s.penalty = pen_c;
+                s.cost = last_cost;
+                s.solve_time_ms = 0.0;
+                a.st[inst] = s;
+            }
+            state = ST_IDLE;
+        }
+    }
+}
+
+}  // namespace nmpc
+
+// =================================================================================================
+// C ABI (include/nmpc_solver.h)
+// =================================================================================================
+using nmpc::KArgs;
+using nmpc::LdsMap;
+
+struct nmpc_handle {
+    nmpc_problem pb;
+    nmpc_opts op;
+    int device;
+    int max_batch;
+    bool alive;
+    LdsMap map;
+    int P;                 // lanes per instance
+    int grid_cap;          // resident waves the launch is sized for
+    unsigned int *d_queue;
+    // staging buffers of the host path
+    double *d_p, *d_u, *d_y0, *d_c0, *d_yout, *d_psi, *d_grad, *d_F1, *d_F2;
+    nmpc_status *d_st;
+    std::string err;
+};
+
+extern "C" {
+
+void nmpc_default_opts(nmpc_opts *o)
+{
+    o->tolerance = 1e-4;
+    o->initial_tolerance = 1e-4;
+    o->delta_tolerance = 1e-4;
+    o->initial_penalty = 1.0;
+    o->penalty_update = 5.0;
+    o->tolerance_update = 0.1;
+    o->sufficient_decrease = 0.1;
+    o->lbfgs_memory = 10;
+    o->max_inner = 500;
+    o->max_outer = 10;
+    o->reserved = 0;
+}
+
+int nmpc_n_u(const nmpc_problem *pb) { return 2 * pb->N; }
+int nmpc_n1(const nmpc_problem *pb) { return 2 * pb->N; }
+int nmpc_n2(const nmpc_problem *pb) { return pb->nobs + pb->ndyn; }
+int nmpc_n_p(const nmpc_problem *pb) { return nmpc::NZ + pb->N + 3 * pb->nobs + 5 * pb->ndyn * pb->N + 3 * pb->N; }
+int nmpc_abi_version(void) { return NMPC_ABI_VERSION; }
+
+static int fail(nmpc_handle *h, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        h->err = what;
+        if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                       \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return fail((h), NMPC_ERR_HIP, #call, e_);       \
+    } while (0)
+
+static LdsMap make_map(const nmpc_problem &pb, int m)
+{
+    LdsMap mp;
+    int o = 0;
+    mp.sc = o;  o += 20;
+    mp.seg = o; o += 5 * pb.N;
+    mp.obs = o; o += 3 * (pb.nobs > 0 ? pb.nobs : 1);
+    mp.f2 = o;  o += pb.nobs + pb.ndyn + 1;
+    mp.rho = o; o += m;
+    o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
+    mp.S = o;   o += 2 * pb.N * m;
+    mp.Y = o;   o += 2 * pb.N * m;
+    mp.total = (o + 1) & ~1;
+    return mp;
+}
+
+int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int max_batch, nmpc_handle **out)
+{
+    if (!pb || !out || max_batch < 1) return NMPC_ERR_BAD_ARG;
+    if (pb->N < 2 || pb->N > 64 || pb->nobs < 0 || pb->nobs > 64 || pb->ndyn < 0 || pb->ndyn > nmpc::NDYN_MAX ||
+        !(pb->ts > 0.0))
+        return NMPC_ERR_BAD_PROBLEM;
+    nmpc_opts op;
+    if (opts) op = *opts; else nmpc_default_opts(&op);
+    if (op.lbfgs_memory < 1 || op.lbfgs_memory > nmpc::MAXMEM || op.max_inner < 1 || op.max_outer < 1)
+        return NMPC_ERR_BAD_OPTS;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
+        return NMPC_ERR_NO_DEVICE;
+    nmpc_handle *h = new nmpc_handle();
+    h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true;
+    h->P = pb->N <= 32 ? 32 : 64;
+    h->map = make_map(*pb, op.lbfgs_memory);
+    h->d_queue = nullptr;
+    h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
+    h->d_st = nullptr;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_queue, sizeof(unsigned int));
+    if (e != hipSuccess) { delete h; return NMPC_ERR_HIP; }
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, device_id);
+    const int K = 64 / h->P;
+    const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * K;
+    if (lds_bytes > 160 * 1024) { hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu > 8) per_cu = 8;             // register budget: <= 2 waves per SIMD
+    if (per_cu < 1) per_cu = 1;
+    h->grid_cap = prop.multiProcessorCount * per_cu;
+    *out = h;
+    return NMPC_OK;
+}
+
+void nmpc_free(nmpc_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipFree(h->d_queue);
+    hipFree(h->d_p); hipFree(h->d_u); hipFree(h->d_y0); hipFree(h->d_c0); hipFree(h->d_yout);
+    hipFree(h->d_psi); hipFree(h->d_grad); hipFree(h->d_F1); hipFree(h->d_F2); hipFree(h->d_st);
+    delete h;
+}
+
+int nmpc_ping(const nmpc_handle *h) { return (h && h->alive) ? NMPC_OK : NMPC_ERR_DEAD_HANDLE; }
+const char *nmpc_last_error(const nmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+static void fill_args(const nmpc_handle *h, KArgs &a, int B)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.pb = h->pb; a.op = h->op; a.map = h->map; a.B = B;
+    a.n_p = nmpc_n_p(&h->pb); a.n_u = nmpc_n_u(&h->pb); a.n1 = nmpc_n1(&h->pb); a.n2 = nmpc_n2(&h->pb);
+    a.queue = h->d_queue;
+}
+
+int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_u, const double *d_y0,
+                            const double *d_c0, double *d_y_out, nmpc_status *d_status, void *stream)
+{
+    if (!h) return NMPC_ERR_BAD_ARG;
+    if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
+    if (B < 0 || B > h->max_batch || (B > 0 && (!d_p || !d_u))) return fail(h, NMPC_ERR_BAD_ARG, "bad batch arguments");
+    if (B == 0) return NMPC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    KArgs a;
+    fill_args(h, a, B);
+    a.p = d_p; a.u = d_u; a.y0 = d_y0; a.c0 = d_c0; a.y_out = d_y_out; a.st = d_status;
+    HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), s));
+    const int K = 64 / h->P;
+    int grid = (B + K - 1) / K;
+    if (grid > h->grid_cap) grid = h->grid_cap;
+    const size_t lds = (size_t)h->map.total * sizeof(double) * K;
+    if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<32>, dim3(grid), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const double *d_u, const double *d_c,
+                           const double *d_y, double *d_psi, double *d_grad, double *d_F1, double *d_F2,
+                           void *stream)
+{
+    if (!h) return NMPC_ERR_BAD_ARG;
+    if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
+    if (B < 0 || B > h->max_batch || (B > 0 && (!d_p || !d_u))) return fail(h, NMPC_ERR_BAD_ARG, "bad batch arguments");
+    if (B == 0) return NMPC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    KArgs a;
+    fill_args(h, a, B);
+    a.p = d_p; a.u = const_cast<double *>(d_u);
+    a.ev_c = d_c; a.ev_y = d_y; a.ev_psi = d_psi; a.ev_grad = d_grad; a.ev_F1 = d_F1; a.ev_F2 = d_F2;
+    const int K = 64 / h->P;
+    const int grid = (B + K - 1) / K;
+    const size_t lds = (size_t)h->map.total * sizeof(double) * K;
+    if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<32>, dim3(grid), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<64>, dim3(grid), dim3(64), lds, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return NMPC_OK;
+}
+
+// ---- host path: staging buffers sized for max_batch, allocated on first use ----
+static int ensure_staging(nmpc_handle *h)
+{
+    if (h->d_p) return NMPC_OK;
+    const size_t B = (size_t)h->max_batch;
+    const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb), n2 = nmpc_n2(&h->pb) + 1;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMalloc((void **)&h->d_p, B * np * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_u, B * nu * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_y0, B * n1 * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_c0, B * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_yout, B * n1 * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_psi, B * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_grad, B * nu * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_F1, B * n1 * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_F2, B * n2 * 8));
+    HIP_TRY(h, hipMalloc((void **)&h->d_st, B * sizeof(nmpc_status)));
+    return NMPC_OK;
+}
+
+int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, const double *y0, const double *c0,
+                          double *y_out, nmpc_status *status)
+{
+    if (!h) return NMPC_ERR_BAD_ARG;
+    if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
+    if (B < 0 || B > h->max_batch || (B > 0 && (!p || !u))) return fail(h, NMPC_ERR_BAD_ARG, "bad batch arguments");
+    if (B == 0) return NMPC_OK;
+    int rc = ensure_staging(h);
+    if (rc) return rc;
+    const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb);
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipMemcpy(h->d_p, p, B * np * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_u, u, B * nu * 8, hipMemcpyHostToDevice));
+    if (y0) HIP_TRY(h, hipMemcpy(h->d_y0, y0, B * n1 * 8, hipMemcpyHostToDevice));
+    if (c0) HIP_TRY(h, hipMemcpy(h->d_c0, c0, B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipEventRecord(e0, nullptr));
+    rc = nmpc_solve_batch_device(h, B, h->d_p, h->d_u, y0 ? h->d_y0 : nullptr, c0 ? h->d_c0 : nullptr,
+                                 h->d_yout, h->d_st, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(e1, nullptr));
+    HIP_TRY(h, hipDeviceSynchronize());
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    HIP_TRY(h, hipMemcpy(u, h->d_u, B * nu * 8, hipMemcpyDeviceToHost));
+    if (y_out) HIP_TRY(h, hipMemcpy(y_out, h->d_yout, B * n1 * 8, hipMemcpyDeviceToHost));
+    if (status) {
+        HIP_TRY(h, hipMemcpy(status, h->d_st, B * sizeof(nmpc_status), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) status[b].solve_time_ms = (double)ms;     // wall time of the whole batch
+    }
+    return NMPC_OK;
+}
+
+int nmpc_eval_batch_host(nmpc_handle *h, int B, const double *p, const double *u, const double *c, const double *y,
+                         double *psi, double *grad, double *F1, double *F2)
+{
+    if (!h) return NMPC_ERR_BAD_ARG;
+    if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
+    if (B < 0 || B > h->max_batch || (B > 0 && (!p || !u))) return fail(h, NMPC_ERR_BAD_ARG, "bad batch arguments");
+    if (B == 0) return NMPC_OK;
+    int rc = ensure_staging(h);
+    if (rc) return rc;
+    const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb), n2 = nmpc_n2(&h->pb);
+    HIP_TRY(h, hipMemcpy(h->d_p, p, B * np * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_u, u, B * nu * 8, hipMemcpyHostToDevice));
+    if (y) HIP_TRY(h, hipMemcpy(h->d_y0, y, B * n1 * 8, hipMemcpyHostToDevice));
+    if (c) HIP_TRY(h, hipMemcpy(h->d_c0, c, B * 8, hipMemcpyHostToDevice));
+    rc = nmpc_eval_batch_device(h, B, h->d_p, h->d_u, c ? h->d_c0 : nullptr, y ? h->d_y0 : nullptr, h->d_psi,
+                                h->d_grad, h->d_F1, h->d_F2, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (psi) HIP_TRY(h, hipMemcpy(psi, h->d_psi, B * 8, hipMemcpyDeviceToHost));
+    if (grad) HIP_TRY(h, hipMemcpy(grad, h->d_grad, B * nu * 8, hipMemcpyDeviceToHost));
+    if (F1) HIP_TRY(h, hipMemcpy(F1, h->d_F1, B * n1 * 8, hipMemcpyDeviceToHost));
+    if (F2 && n2) HIP_TRY(h, hipMemcpy(F2, h->d_F2, B * n2 * 8, hipMemcpyDeviceToHost));
+    return NMPC_OK;
+}
+
+// ---- arithmetic primitives, for bit-level checks against the oracle ----
+__global__ void nmpc_test_sincos_kernel(int n, const double *x, double *s, double *c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) nmpc::sincos_cw(x[i], s[i], c[i]);
+}
+__global__ void nmpc_test_divsqrt_kernel(int n, const double *a, const double *b, double *q, double *r)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { q[i] = a[i] / b[i]; r[i] = sqrt(a[i]); }
+}
+
+static int run_unary_test(nmpc_handle *h, int n, const double *x0, const double *x1, double *o0, double *o1, int which)
+{
+    if (!h || n < 0 || !x0 || !o0 || !o1) return NMPC_ERR_BAD_ARG;
+    if (n == 0) return NMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    double *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) HIP_TRY(h, hipMalloc((void **)&d[i], (size_t)n * 8));
+    HIP_TRY(h, hipMemcpy(d[0], x0, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (x1) HIP_TRY(h, hipMemcpy(d[1], x1, (size_t)n * 8, hipMemcpyHostToDevice));
+    const int blocks = (n + 255) / 256;
+    if (which == 0) hipLaunchKernelGGL(nmpc_test_sincos_kernel, dim3(blocks), dim3(256), 0, nullptr, n, d[0], d[2], d[3]);
+    else hipLaunchKernelGGL(nmpc_test_divsqrt_kernel, dim3(blocks), dim3(256), 0, nullptr, n, d[0], d[1], d[2], d[3]);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(o0, d[2], (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(o1, d[3], (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) hipFree(d[i]);
+    return NMPC_OK;
+}
+
+int nmpc_test_sincos_host(nmpc_handle *h, int n, const double *x, double *out_s, double *out_c)
+{
+    return run_unary_test(h, n, x, nullptr, out_s, out_c, 0);
+}
+int nmpc_test_divsqrt_host(nmpc_handle *h, int n, const double *a, const double *b, double *out_div, double *out_sqrt)
+{
+    if (!b) return NMPC_ERR_BAD_ARG;
+    return run_unary_test(h, n, a, b, out_div, out_sqrt, 1);
+}
+
+}  // extern "C"
