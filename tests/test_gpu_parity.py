@@ -1,0 +1,153 @@
+"""GPU: the HIP path, called through the C ABI, against the CPU oracle and the committed goldens.
+
+The bar is bit-exact: kernels and oracle implement the same canonical f64 arithmetic (DESIGN.md
+section 4), so controls, multipliers, iteration counts and status words must be identical.  Against the
+reference-derived goldens (different summation order, libm sin/cos) the tolerance is RTOL."""
+import numpy as np
+import pytest
+
+from conftest import STATUS_FIELDS, VARIANTS, oracle_for
+from mpc_trajectory_generator_amd import named_config
+from mpc_trajectory_generator_amd.harness import synthetic_batch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def solvers():
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    made = {}
+
+    def get(name, **opts):
+        key = (name, tuple(sorted(opts.items())))
+        if key not in made:
+            made[key] = BatchSolver(named_config(name), max_batch=8192, **opts)
+        return made[key]
+    yield get
+    for s in made.values():
+        s.close()
+
+
+def assert_same_solution(gpu, cpu):
+    (u, y, st), (uo, yo, sto) = gpu, cpu
+    for f in STATUS_FIELDS:
+        assert np.array_equal(st[f], sto[f]), f
+    assert np.array_equal(u, uo)
+    assert np.array_equal(y, yo)
+
+
+def test_native_library_loaded(solvers):
+    s = solvers("cfg1")
+    s.ping()
+    maps = open("/proc/self/maps").read()
+    assert "libnmpc_hip.so" in maps
+
+
+def test_primitives_bit_exact(solvers):
+    s, o = solvers("cfg1"), oracle_for(named_config("cfg1"))
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-20, 20, 4000), rng.uniform(-1e3, 1e3, 500), [0.0, np.pi / 2, -np.pi, 1e-300]])
+    sn, cs = s.test_sincos(x)
+    ref = np.array([o.sincos(v) for v in x])
+    assert np.array_equal(sn, ref[:, 0]) and np.array_equal(cs, ref[:, 1])
+    a = np.abs(rng.normal(0, 1, 50000)) * 10.0 ** rng.integers(-30, 30, 50000)
+    b = rng.normal(0, 1, 50000) * 10.0 ** rng.integers(-30, 30, 50000)
+    q, r = s.test_divsqrt(a, b)
+    assert np.array_equal(q, a / b) and np.array_equal(r, np.sqrt(a))       # IEEE division and sqrt
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_cost_layer_vs_oracle_and_golden(golden, solvers, name):
+    d, cfg = golden[name], named_config(VARIANTS[name])
+    s, o = solvers(VARIANTS[name]), oracle_for(cfg)
+    n = len(d["u"])
+    f, g, F1, F2 = s.evaluate(d["p"], d["u"])
+    assert np.max(np.abs(f - d["f"]) / np.abs(d["f"])) <= RTOL
+    assert np.max(np.abs(g - d["grad_f"]) / np.max(np.abs(d["grad_f"]), axis=1, keepdims=True)) <= RTOL
+    assert np.max(np.abs(F1 - d["F1"])) <= RTOL * max(1.0, np.max(np.abs(d["F1"])))
+    assert np.max(np.abs(F2 - d["F2"])) <= RTOL * max(1.0, np.max(np.abs(d["F2"])))
+    for j, (c, y) in enumerate(zip(d["xi_c"], d["xi_y"])):
+        psi, gp, F1, F2 = s.evaluate(d["p"], d["u"], np.full(n, c), np.tile(y, (n, 1)))
+        assert np.max(np.abs(psi - d["psi"][:, j]) / np.abs(d["psi"][:, j])) <= RTOL
+        assert np.max(np.abs(gp - d["grad_psi"][:, j]) /
+                      np.max(np.abs(d["grad_psi"][:, j]), axis=1, keepdims=True)) <= RTOL
+        for i in range(n):
+            po, go, F1o, F2o = o.eval(d["p"][i], d["u"][i], c, y)
+            assert psi[i] == po and np.array_equal(gp[i], go)
+            assert np.array_equal(F1[i], F1o) and np.array_equal(F2[i], F2o)
+
+
+@pytest.mark.parametrize("name,scene,B", [("cfg1", 11, 96), ("cfg1", 1, 33), ("cfg2", 11, 24)])
+def test_solve_cold_start_bit_exact(solvers, name, scene, B):
+    cfg = named_config(name)
+    P = synthetic_batch(cfg, scene, B, 12345)
+    assert_same_solution(solvers(name).solve(P), oracle_for(cfg).solve_batch(P, threads=8))
+
+
+def test_solve_nobs50_and_dynamic_obstacles(solvers):
+    cfg = named_config("cfg3")
+    P = synthetic_batch(cfg, 11, 32, 12345, synthetic_circles=True)
+    assert_same_solution(solvers("cfg3").solve(P), oracle_for(cfg).solve_batch(P, threads=8))
+    cfg = named_config("cfg4")
+    P = synthetic_batch(cfg, 11, 32, 12345, random_dyn=True)
+    assert_same_solution(solvers("cfg4").solve(P), oracle_for(cfg).solve_batch(P, threads=8))
+
+
+def test_solve_warm_start_multipliers_penalty(solvers):
+    cfg = named_config("cfg1")
+    s, o = solvers("cfg1"), oracle_for(cfg)
+    P = synthetic_batch(cfg, 11, 40, 7)
+    u, y, st = s.solve(P)
+    rng = np.random.default_rng(5)
+    c0 = rng.choice([1.0, 5.0, 25.0], size=len(P))
+    gpu = s.solve(P, u0=u, y0=y, c0=c0)
+    cpu = o.solve_batch(P, u0=u, y0=y, c0=c0, threads=8)
+    assert_same_solution(gpu, cpu)
+    assert gpu[2]["num_inner_iterations"].sum() < st["num_inner_iterations"].sum()
+
+
+def test_edge_cases(solvers):
+    cfg = named_config("cfg1")
+    s, o = solvers("cfg1"), oracle_for(cfg)
+    # ragged batch sizes around the two-instances-per-wave packing, and B = 1
+    for B in (1, 2, 3, 65):
+        P = synthetic_batch(cfg, 1, B, 100 + B)
+        assert_same_solution(s.solve(P), o.solve_batch(P, threads=4))
+    # empty batch
+    u, y, st = s.solve(np.zeros((0, cfg.n_p)))
+    assert u.shape == (0, cfg.n_u) and st.shape == (0,)
+    # iteration caps: tiny budgets must stop with NotConvergedIterations, identically
+    s2, o2 = solvers("cfg1", max_inner=7, max_outer=3), oracle_for(cfg, max_inner=7, max_outer=3)
+    P = synthetic_batch(cfg, 11, 16, 9)
+    gpu, cpu = s2.solve(P), o2.solve_batch(P, threads=4)
+    assert_same_solution(gpu, cpu)
+    assert np.all(gpu[2]["exit_status"] == 1) and np.all(gpu[2]["num_outer_iterations"] <= 3)
+    assert np.all(gpu[2]["num_inner_iterations"] <= 3 * 7)
+    # wrong parameter count is an error, not a crash (OpEn error code 3003)
+    from mpc_trajectory_generator_amd.solver import SolverError
+    with pytest.raises(SolverError):
+        s.solve(np.zeros((2, cfg.n_p - 1)))
+
+
+def test_full_size_batch_properties(solvers):
+    """BASELINE config 1 at full size (B = 8192): size-independent properties + sampled oracle parity."""
+    cfg = named_config("cfg1")
+    s, o = solvers("cfg1"), oracle_for(cfg)
+    P = synthetic_batch(cfg, 11, 8192, 0)
+    u, y, st = s.solve(P)
+    assert np.all(np.isfinite(u))
+    assert u[:, 0::2].min() >= cfg.lin_vel_min and u[:, 0::2].max() <= cfg.lin_vel_max
+    assert np.abs(u[:, 1::2]).max() <= cfg.ang_vel_max
+    conv = st["exit_status"] == 0
+    assert np.all(st["f2_norm"][conv] <= 1e-4 + 1e-12) and np.all(st["delta_y_norm_over_c"][conv] <= 1e-4 + 1e-12)
+    # permutation invariance: an instance's result does not depend on its slot / wave-mate
+    perm = np.random.default_rng(0).permutation(8192)
+    u2, y2, st2 = s.solve(P[perm])
+    assert np.array_equal(u2, u[perm]) and np.array_equal(st2["num_inner_iterations"], st["num_inner_iterations"][perm])
+    # sampled oracle parity
+    idx = np.random.default_rng(1).choice(8192, 64, replace=False)
+    uo, yo, sto = o.solve_batch(P[idx], threads=8)
+    assert np.array_equal(u[idx], uo) and np.array_equal(y[idx], yo)
+    for f in STATUS_FIELDS:
+        assert np.array_equal(st[f][idx], sto[f]), f
