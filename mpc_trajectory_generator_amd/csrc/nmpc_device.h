@@ -18,11 +18,23 @@
 namespace nmpc {
 
 // ---------------------------------------------------------------------------------------------
-// cross-lane primitives
+// cross-lane primitives: DPP row operations (VALU speed, no LDS traffic) + gfx950 permlane swaps
 // ---------------------------------------------------------------------------------------------
+// DPP control words (CDNA ISA): quad_perm 0x00-0xFF, row_shl:n 0x100+n, row_shr:n 0x110+n,
+// wave_shl:1 0x130, wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141, row_bcast:15 0x142,
+// row_bcast:31 0x143, row_newbcast:n 0x150+n
+template <int CTRL, int ROW_MASK = 0xF, bool BOUND_CTRL = true>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    // lanes whose source is out of range (BOUND_CTRL) or whose row is masked off read 0.0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, BOUND_CTRL);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, BOUND_CTRL);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double lane_get(double v, int src_lane)
 {
-    // ds_bpermute_b32 x2: pull `v` from an arbitrary lane of the wave
+    // ds_bpermute_b32 x2: pull `v` from an arbitrary lane of the wave (slow path, rarely used)
     const int idx = src_lane << 2;
     int lo = __builtin_amdgcn_ds_bpermute(idx, __double2loint(v));
     int hi = __builtin_amdgcn_ds_bpermute(idx, __double2hiint(v));
@@ -34,34 +46,50 @@ __device__ __forceinline__ int lane_get_i(int v, int src_lane)
     return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
 }
 
-// sum over the P lanes of the group, result in every lane (butterfly; a + b == b + a bitwise, so
-// every lane holds the value of the adjacent-pair tree)
+// v_permlane16_swap: exchanges odd rows of the first operand with even rows of the second.
+// swap(x, x) -> first = [r0 r0 r2 r2], second = [r1 r1 r3 r3] (rows of 16 lanes)
+__device__ __forceinline__ void row_pair_split(double v, double &even_rows, double &odd_rows)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    even_rows = __hiloint2double(hi[0], lo[0]);
+    odd_rows = __hiloint2double(hi[1], lo[1]);
+}
+
+// sum over the P lanes of the group, result in every lane.  Butterfly over lane^1, ^2, ^4, ^8, ^16
+// (^32); a + b == b + a bitwise, so every lane ends with the value of the adjacent-pair tree.
 template <int P>
 __device__ __forceinline__ double group_sum(double v, int lane)
 {
-#pragma unroll
-    for (int off = 1; off < P; off <<= 1) v = v + lane_get(v, lane ^ off);
+    (void)lane;
+    v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v);      // row_half_mirror: the other quad of the 8-lane block
+    v = v + dpp_mov<0x140>(v);      // row_mirror: the other 8-lane block of the row
+    {
+        double a, b;
+        row_pair_split(v, a, b);    // the other row of the 32-lane half
+        v = a + b;
+    }
+    if (P == 64) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
     return v;
 }
 
-// inclusive prefix sum over the stages of the group
+// inclusive prefix sum over the stages of the group: Kogge-Stone inside 16-lane rows, then carries
 template <int P>
 __device__ __forceinline__ double group_prefix(double v, int lane)
 {
-    const int r = lane & 15;
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-        const double o = lane_get(v, (lane - off) & 63);
-        if (r >= off) v = v + o;
-    }
-    {   // odd rows add the last lane of the row before them
-        const double c = lane_get(v, ((lane & ~15) - 1) & 63);
-        if (lane & 16) v = v + c;
-    }
-    if (P == 64) {
-        const double c = lane_get(v, 31);
-        if (lane & 32) v = v + c;
-    }
+    v = v + dpp_mov<0x111>(v);                  // row_shr:1, zero fill
+    v = v + dpp_mov<0x112>(v);
+    v = v + dpp_mov<0x114>(v);
+    v = v + dpp_mov<0x118>(v);
+    v = v + dpp_mov<0x142, 0xA, false>(v);      // row_bcast:15 into rows 1 and 3
+    if (P == 64) v = v + dpp_mov<0x143, 0xC, false>(v);   // row_bcast:31 into rows 2 and 3
+    (void)lane;
     return v;
 }
 
@@ -69,19 +97,21 @@ __device__ __forceinline__ double group_prefix(double v, int lane)
 template <int P>
 __device__ __forceinline__ double group_suffix(double v, int lane)
 {
-    const int r = lane & 15;
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-        const double o = lane_get(v, (lane + off) & 63);
-        if (r + off <= 15) v = v + o;
-    }
+    v = v + dpp_mov<0x101>(v);                  // row_shl:1, zero fill
+    v = v + dpp_mov<0x102>(v);
+    v = v + dpp_mov<0x104>(v);
+    v = v + dpp_mov<0x108>(v);
     {   // even rows add the first lane of the row after them
-        const double c = lane_get(v, ((lane | 15) + 1) & 63);
-        if (!(lane & 16)) v = v + c;
+        const double first = dpp_mov<0x150, 0xF, false>(v);          // row_newbcast:0
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(first), 0, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(first), 0, false, false);
+        v = v + __hiloint2double(hi[1], lo[1]);                      // [r1 0 r3 0]
     }
     if (P == 64) {
-        const double c = lane_get(v, 32);
-        if (!(lane & 32)) v = v + c;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 32);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 32);
+        const double c = __hiloint2double(hi, lo);
+        v = v + ((lane & 32) ? 0.0 : c);
     }
     return v;
 }
@@ -90,13 +120,13 @@ __device__ __forceinline__ double group_suffix(double v, int lane)
 template <int P>
 __device__ __forceinline__ double from_prev(double v, int lane, double fill)
 {
-    const double o = lane_get(v, (lane - 1) & 63);
+    const double o = dpp_mov<0x138>(v);         // wave_shr:1
     return (lane & (P - 1)) == 0 ? fill : o;
 }
 template <int P>
 __device__ __forceinline__ double from_next(double v, int lane)
 {
-    const double o = lane_get(v, (lane + 1) & 63);
+    const double o = dpp_mov<0x130>(v);         // wave_shl:1
     return (lane & (P - 1)) == P - 1 ? 0.0 : o;
 }
 

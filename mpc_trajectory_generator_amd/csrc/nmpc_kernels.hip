@@ -20,6 +20,7 @@ namespace nmpc {
 constexpr int NZ = 20;         // reference configs/default.yaml:35
 constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
 constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
+constexpr int SEG_STRIDE = 6;  // doubles per reference segment in LDS
 
 // PANOC constants
 constexpr double GAMMA_L_COEFF = 0.95;
@@ -36,7 +37,7 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 // LDS slice of one group (offsets in doubles)
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
-    int seg;     // 5 per reference segment: s1x s1y dx dy inv
+    int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
     int rho;     // m
@@ -50,6 +51,7 @@ struct KArgs {
     LdsMap map;
     int B;
     int n_p, n_u, n1, n2;
+    double inv_ts;
     const double *p;
     double *u;
     const double *y0;
@@ -115,7 +117,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, cons
         const double ax = pr[3 * t], ay = pr[3 * t + 1];
         const double bx = pr[3 * t + 3], by = pr[3 * t + 4];
         const double dx = bx - ax, dy = by - ay;
-        double *sg = L + a.map.seg + 5 * t;
+        double *sg = L + a.map.seg + SEG_STRIDE * t;
         sg[0] = ax;
         sg[1] = ay;
         sg[2] = dx;
@@ -129,13 +131,13 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, cons
 // psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); F2_k left in the LDS slice
 // ---------------------------------------------------------------------------------------------
 template <int P>
-__device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, int t, double zv, double zw,
+__device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
                                          double &gw, double &av_out, double &aw_out)
 {
     const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
-    const double ts = a.pb.ts, inv_ts = 1.0 / a.pb.ts;
+    const double ts = a.pb.ts, inv_ts = a.inv_ts;
     const bool in = t < N;
     const double *sc = L + a.map.sc;
     const double x0 = sc[SC_X0], y0 = sc[SC_Y0], th0 = sc[SC_TH0];
@@ -168,7 +170,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, in
     int bi = 0;
     {
         const double *sg = L + a.map.seg;
-        for (int i = 0; i < N - 1; ++i, sg += 5) {
+        for (int i = 0; i < N - 1; ++i, sg += SEG_STRIDE) {
             const double px = xn - sg[0], py = yn - sg[1];
             const double dot = fma(px, sg[2], py * sg[3]);
             const double that = dot * sg[4];
@@ -199,16 +201,25 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, in
     aw_out = aw;
     const double fsum = group_sum<P>(acc, lane);
 
-    // obstacle penalties on the post-update state (:106-119)
+    // obstacle penalties on the post-update state (:106-119).  F2_k = sum_t max(0, h_kt); an obstacle
+    // that no stage of either instance in this wave touches contributes exactly 0 and is skipped
+    // (wave-uniform branch); its bit in `act` stays clear so the adjoint sweep skips it too.
     double pen = 0.0;
+    unsigned long long act = 0ull;
+    unsigned act_dyn = 0u;
     {
         const double *ob = L + a.map.obs;
         for (int k = 0; k < nobs; ++k, ob += 3) {
             const double dx = xn - ob[0], dy = yn - ob[1];
             const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));                   // (:112)
-            const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
-            if (t == 0) L[a.map.f2 + k] = f2;
-            pen = fma(f2, f2, pen);
+            const double hm = in ? fmax(h, 0.0) : 0.0;
+            double f2 = 0.0;
+            if (__any(hm > 0.0)) {
+                act |= 1ull << k;
+                f2 = group_sum<P>(hm, lane);
+                pen = fma(f2, f2, pen);
+            }
+            if (t == 0) L[f2off + k] = f2;
         }
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
@@ -217,9 +228,14 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, in
                 const double ea = fma(dx, dyn.ca[k], dy * dyn.sa[k]);
                 const double eb = fma(dx, dyn.sa[k], -(dy * dyn.ca[k]));
                 const double h = fma(-(eb * eb), dyn.iry2[k], fma(-(ea * ea), dyn.irx2[k], 1.0));   // (:118)
-                const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
-                if (t == 0) L[a.map.f2 + nobs + k] = f2;
-                pen = fma(f2, f2, pen);
+                const double hm = in ? fmax(h, 0.0) : 0.0;
+                double f2 = 0.0;
+                if (__any(hm > 0.0)) {
+                    act_dyn |= 1u << k;
+                    f2 = group_sum<P>(hm, lane);
+                    pen = fma(f2, f2, pen);
+                }
+                if (t == 0) L[f2off + nobs + k] = f2;
             }
         }
     }
@@ -231,7 +247,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, in
     // ---- adjoint sweep (what CasADi reverse AD generated for the reference) ----
     double gx, gy;
     {
-        const double *sg = L + a.map.seg + 5 * bi;          // arg-min segment of this stage
+        const double *sg = L + a.map.seg + SEG_STRIDE * bi;          // arg-min segment of this stage
         const double px = xn - sg[0], py = yn - sg[1];
         const double dot = fma(px, sg[2], py * sg[3]);
         const double that = dot * sg[4];
@@ -244,9 +260,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, in
         gy = two_q * fma(m, sg[3], -ey);
     }
     {
-        const double *ob = L + a.map.obs;
-        const double *f2 = L + a.map.f2;
-        for (int k = 0; k < nobs; ++k, ob += 3) {
+        const double *f2 = L + f2off;
+        while (act) {                                        // only the circles some stage is inside of
+            const int k = __builtin_ctzll(act);
+            act &= act - 1;
+            const double *ob = L + a.map.obs + 3 * k;
             const double wk = -2.0 * (c * f2[k]);
             const double dx = xn - ob[0], dy = yn - ob[1];
             const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));
@@ -254,7 +272,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int lane, in
         }
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
-            if (k < ndyn) {
+            if (act_dyn & (1u << k)) {
                 const double wk = -2.0 * (c * f2[nobs + k]);
                 const double dx = xn - dyn.ex[k], dy = yn - dyn.ey[k];
                 const double ea = fma(dx, dyn.ca[k], dy * dyn.sa[k]);
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
     const double yv = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + t] : 0.0;
     const double yw = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + N + t] : 0.0;
     double psi, pen, gv, gw, av, aw;
-    eval_psi<P>(a, L, lane, t, zv, zw, c, yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
+    eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, c, yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
     if (inst >= a.B) return;
     if (t == 0 && a.ev_psi) a.ev_psi[b] = psi;
     if (t < N) {
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
         // ------------------------------------------------------------------ one evaluation of psi per group
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         const bool wg = __any(live && need_grad);
-        eval_psi<P>(a, L, lane, t, zv, zw, pen_c, yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
+        eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, pen_c, yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
         if (!live) continue;
 
         // ------------------------------------------------------------------ consume it
@@ -652,6 +670,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 
 }  // namespace nmpc
 
+#include "nmpc_solve_dual.h"
+
 // =================================================================================================
 // C ABI (include/nmpc_solver.h)
 // =================================================================================================
@@ -717,9 +737,9 @@ static LdsMap make_map(const nmpc_problem &pb, int m)
     LdsMap mp;
     int o = 0;
     mp.sc = o;  o += 20;
-    mp.seg = o; o += 5 * pb.N;
+    mp.seg = o; o += nmpc::SEG_STRIDE * pb.N;
     mp.obs = o; o += 3 * (pb.nobs > 0 ? pb.nobs : 1);
-    mp.f2 = o;  o += pb.nobs + pb.ndyn + 1;
+    mp.f2 = o;  o += 2 * (pb.nobs + pb.ndyn + 1);     // one F2 array per half (dual kernel)
     mp.rho = o; o += m;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
     mp.S = o;   o += 2 * pb.N * m;
@@ -753,8 +773,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (e != hipSuccess) { delete h; return NMPC_ERR_HIP; }
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, device_id);
-    const int K = 64 / h->P;
-    const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * K;
+    const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * 2;       // eval kernel: two slices per wave
     if (lds_bytes > 160 * 1024) { hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 8) per_cu = 8;             // register budget: <= 2 waves per SIMD
@@ -783,6 +802,7 @@ static void fill_args(const nmpc_handle *h, KArgs &a, int B)
     a.pb = h->pb; a.op = h->op; a.map = h->map; a.B = B;
     a.n_p = nmpc_n_p(&h->pb); a.n_u = nmpc_n_u(&h->pb); a.n1 = nmpc_n1(&h->pb); a.n2 = nmpc_n2(&h->pb);
     a.queue = h->d_queue;
+    a.inv_ts = 1.0 / h->pb.ts;
 }
 
 int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_u, const double *d_y0,
@@ -798,11 +818,11 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     fill_args(h, a, B);
     a.p = d_p; a.u = d_u; a.y0 = d_y0; a.c0 = d_c0; a.y_out = d_y_out; a.st = d_status;
     HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), s));
-    const int K = 64 / h->P;
-    int grid = (B + K - 1) / K;
-    if (grid > h->grid_cap) grid = h->grid_cap;
-    const size_t lds = (size_t)h->map.total * sizeof(double) * K;
-    if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<32>, dim3(grid), dim3(64), lds, s, a);
+    // one instance per wave: N_hor <= 32 runs the dual-evaluation kernel (two query points per
+    // pass), longer horizons the one-point-per-pass kernel with the whole wave as one group
+    const int grid = B < h->grid_cap ? B : h->grid_cap;
+    const size_t lds = (size_t)h->map.total * sizeof(double);
+    if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;

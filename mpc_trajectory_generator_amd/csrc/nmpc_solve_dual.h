@@ -1,0 +1,375 @@
+// nmpc_solve_dual.h -- the N_hor <= 32 solver: ONE problem instance per wavefront, the two 32-lane
+// halves of the wave evaluate psi at TWO query points per pass.
+//
+// Why: at B = 8192 the batch is bounded by the latency of its slowest instance (thousands of
+// PANOC iterations), not by chip throughput, so the kernel minimises evaluation passes per
+// iteration.  PANOC's iteration k >= 1 needs psi(u_bar) for the Lipschitz test and then
+// psi, grad psi at the line-search trial u+ = u - (1-tau) r - tau d.  Both are known before either
+// is evaluated (the L-BFGS update is computed tentatively), so half 0 evaluates u_bar while half 1
+// evaluates u+(tau = 1); further line-search trials are evaluated two at a time (tau, tau/2), and
+// PANOC's initialisation evaluates u and u + h together.  If the Lipschitz test fails the
+// speculative half is discarded and the sequential path is followed.  Results, iteration counts
+// and evaluation counters are exactly those of the sequential algorithm (oracle/nmpc_oracle.c).
+//
+// Lane (h, t): h = lane >> 5 selects the query point, t = lane & 31 is the stage.  All solver state
+// is replicated in both halves; results cross halves with v_permlane32_swap.
+#pragma once
+
+namespace nmpc {
+
+// value held by the same stage in half 0 / half 1, delivered to both halves
+__device__ __forceinline__ void both_halves(double v, double &from_h0, double &from_h1)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    from_h0 = __hiloint2double(hi[0], lo[0]);
+    from_h1 = __hiloint2double(hi[1], lo[1]);
+}
+
+enum : int { D_INIT = 0, D_LIP, D_ITER, D_LS, D_ALM };
+
+// forward-backward envelope at the point whose cost / gradient / gradient step / half step are given
+template <int P>
+__device__ __forceinline__ double fbe_value(double cost, double gamma, double sv, double sw, double hv, double hw,
+                                            double gv, double gw, int lane)
+{
+    const double e1 = sv - hv, e2 = sw - hw;
+    const double dist2 = group_sum<P>(fma(e1, e1, e2 * e2), lane);
+    const double gg = hdot<P>(gv, gw, gv, gw, lane);
+    return cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
+}
+
+// gradient step x - gamma g and its projection on U (lanes beyond the horizon stay zero)
+#define NMPC_HALF_STEP(xv, xw)                                   \
+    do {                                                         \
+        sv_ = fma(-gamma, gv, (xv)); sw_ = fma(-gamma, gw, (xw)); \
+        hv = in ? clampd(sv_, vmin, vmax) : sv_;                 \
+        hw = in ? clampd(sw_, -wmax, wmax) : sw_;                \
+    } while (0)
+
+__global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
+{
+    constexpr int P = 32;
+    extern __shared__ double lds[];
+    double *L = lds;
+    const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
+    const int N = a.pb.N, m = a.op.lbfgs_memory;
+    const bool in = t < N;
+    const int f2off = a.map.f2 + h * (a.n2 + 1);
+    double2 *LS = reinterpret_cast<double2 *>(L + a.map.S);
+    double2 *LY = reinterpret_cast<double2 *>(L + a.map.Y);
+    double *Lrho = L + a.map.rho;
+    const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
+    const unsigned max_inner = (unsigned)a.op.max_inner;
+
+    for (;;) {
+        // ------------------------------------------------------------------ next instance from the queue
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(a.queue, 1u);
+        nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+        if (nxt >= (unsigned)a.B) break;
+        const int inst = (int)nxt;
+
+        double vref;
+        DynStage dyn;
+        prepare_instance<P>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+
+        // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
+        const double *u0 = a.u + (size_t)inst * a.n_u;
+        double uv = in ? u0[2 * t] : 0.0, uw = in ? u0[2 * t + 1] : 0.0;
+        double yv = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + t] : 0.0;
+        double yw = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + N + t] : 0.0;
+        double ypv = yv, ypw = yw;
+        double gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
+        double qv = 0, qw = 0;                    // gradient_u_previous (AKKT residual)
+        double osv = 0, osw = 0, ogv = 0, ogw = 0;
+        double pv = 0, pw = 0;                    // line-search trial point of THIS half
+        double zv = 0, zw = 0;                    // query point of THIS half
+        bool need_grad = true;
+        double cost = 0, Lc = 0, gamma = 0, sigma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0, norm_h = 0, H0 = 1;
+        int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
+        bool lb_first = true;
+        // tentative L-BFGS update of the current iteration (committed when the Lipschitz test passes)
+        int n_active = 0, n_head = 0;
+        bool n_first = true, n_take_old = false;
+        double n_H0 = 1;
+        unsigned num_iter = 0;
+        const double c0 = a.c0 ? a.c0[inst] : 0.0;
+        double pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
+        double eps_nu = a.op.initial_tolerance;
+        double dy_norm = 0, f2_norm = 0, dy_norm_plus = DBL_MAX, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
+        int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
+        unsigned inner_total = 0, n_cost = 0, n_grad = 0;
+
+        // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
+        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
+        bool running = true;
+
+        for (;;) {
+            // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
+            if (f_back) {
+                f_back = false;
+                lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
+                Lc *= 2.0; gamma /= 2.0;
+                NMPC_HALF_STEP(uv, uw);
+                rv = uv - hv; rw = uw - hw;
+                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                norm_r = sqrt(nr2);
+                lip_it++;
+                zv = hv; zw = hw; need_grad = iteration == 0; state = D_LIP;
+            }
+            // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1)
+            if (f_trials) {
+                f_trials = false;
+                const double th_ = h ? tau / 2.0 : tau;
+                const double omt = 1.0 - th_;
+                pv = fma(-th_, dv, fma(-omt, rv, uv));
+                pw = fma(-th_, dw, fma(-omt, rw, uw));
+                zv = pv; zw = pw; need_grad = true; state = D_LS;
+            }
+            // ---------------------------------------------------------------- an iteration finished
+            if (f_end) {
+                f_end = false;
+                iteration++;
+                // OpEn: while step() && num_iter < max_iter { num_iter++ }
+                if (!(num_iter < max_inner)) f_done = true;
+                else { num_iter++; f_begin = true; }
+            }
+            // ---------------------------------------------------------------- start of a PANOC step
+            if (f_begin) {
+                f_begin = false;
+                rv = uv - hv; rw = uw - hw;
+                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                norm_r = sqrt(nr2);
+                bool exit_now = false;
+                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test
+                    const double a1 = rv / gamma + (gv - qv), a2 = rw / gamma + (gw - qw);
+                    exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu);
+                }
+                if (exit_now) {
+                    f_done = true;
+                } else if (iteration == 0) {
+                    // psi and grad psi at u_bar serve both the Lipschitz test and the first FB step
+                    lip_it = 0;
+                    zv = hv; zw = hw; need_grad = true; state = D_LIP;
+                } else {
+                    lip_it = 0;
+                    // ---- tentative L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
+                    n_first = lb_first; n_head = lb_head; n_active = lb_active; n_H0 = H0; n_take_old = false;
+                    if (lb_first) {
+                        n_first = false; n_take_old = true;
+                    } else {
+                        const double s1 = uv - osv, s2 = uw - osw, y1 = rv - ogv, y2 = rw - ogw;
+                        const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
+                        bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
+                        if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
+                        if (__any(ok)) {
+                            n_take_old = true;
+                            n_head = lb_head == 0 ? m - 1 : lb_head - 1;
+                            if (in && h == 0) { LS[n_head * N + t] = make_double2(s1, s2); LY[n_head * N + t] = make_double2(y1, y2); }
+                            if (lane == 0) Lrho[n_head] = 1.0 / ys;
+                            n_H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
+                            if (n_active < m) n_active++;
+                            NMPC_WAVE_SYNC();
+                        }
+                    }
+                    // ---- d = H r, two-loop recursion over the tentative buffer ----
+                    dv = rv; dw = rw;
+                    {
+                        double alpha[MAXMEM];
+#pragma unroll
+                        for (int k = 0; k < MAXMEM; ++k) {
+                            alpha[k] = 0.0;
+                            if (k < n_active) {
+                                int slot = n_head + k; if (slot >= m) slot -= m;
+                                const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
+                                const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
+                                const double al = Lrho[slot] * hdot<P>(s.x, s.y, dv, dw, lane);
+                                alpha[k] = al;
+                                dv = fma(-al, y.x, dv); dw = fma(-al, y.y, dw);
+                            }
+                        }
+                        if (n_active > 0) { dv = n_H0 * dv; dw = n_H0 * dw; }
+#pragma unroll
+                        for (int k = MAXMEM - 1; k >= 0; --k) {
+                            if (k < n_active) {
+                                int slot = n_head + k; if (slot >= m) slot -= m;
+                                const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
+                                const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
+                                const double be = Lrho[slot] * hdot<P>(y.x, y.y, dv, dw, lane);
+                                const double ab = alpha[k] - be;
+                                dv = fma(ab, s.x, dv); dw = fma(ab, s.y, dw);
+                            }
+                        }
+                    }
+                    const double sg = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                    rhs_ls = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane) - sg * nr2;
+                    tau = 1.0; ls_n = 0;
+                    const double omt = 1.0 - tau;
+                    pv = fma(-tau, dv, fma(-omt, rv, uv));
+                    pw = fma(-tau, dw, fma(-omt, rw, uw));
+                    zv = h ? pv : hv; zw = h ? pw : hw;                  // half 0: u_bar, half 1: u+(tau = 1)
+                    need_grad = true; state = D_ITER;
+                }
+            }
+            // ---------------------------------------------------------------- the inner solver returned
+            if (f_done) {
+                f_done = false;
+                inner_status = num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
+                inner_total += num_iter;
+                last_fpr = norm_r; last_cost = cost;
+                uv = hv; uw = hw;                                        // PANOC returns the feasible half step
+                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
+                if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
+                else { zv = uv; zw = uw; need_grad = false; state = D_ALM; }
+            }
+            // ---------------------------------------------------------------- start an inner solve
+            if (f_start) {
+                f_start = false;
+                yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);      // y <- Pi_Y(y)
+                lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                // init evaluates u (half 0) and u + h (half 1), h_i = max(1e-6 u_i, 1e-12)
+                const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
+                const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
+                norm_h = sqrt(group_sum<P>(in ? fma(h1, h1, h2 * h2) : 0.0, lane));
+                zv = h ? (in ? uv + h1 : 0.0) : uv;
+                zw = h ? (in ? uw + h2 : 0.0) : uw;
+                need_grad = true; state = D_INIT;
+            }
+            if (!running) break;
+
+            // ================================================================ one pass: psi at two points
+            double psi, pen, egv = 0, egw = 0, eav, eaw;
+            eval_psi<P>(a, L, f2off, lane, t, zv, zw, pen_c, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+            double psiA, psiB, gAv, gBv, gAw, gBw;
+            both_halves(psi, psiA, psiB);
+            both_halves(egv, gAv, gBv);
+            both_halves(egw, gAw, gBw);
+
+            if (state == D_INIT) {
+                n_grad += 2;
+                cost = psiA; gv = gAv; gw = gAw;
+                const double d1 = gBv - gAv, d2 = gBw - gAw;
+                Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / norm_h;
+                gamma = GAMMA_L_COEFF / fmax(Lc, MIN_LIPSCHITZ_CONSTANT);
+                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                NMPC_HALF_STEP(uv, uw);
+                f_begin = true;
+            } else if (state == D_LIP || state == D_ITER) {
+                // Lipschitz test on psi(u_bar) (half 0).  D_LIP: sequential (iteration 0, or after a
+                // failed speculative pass; the L-BFGS buffer is empty there).  D_ITER: half 1 holds the
+                // speculative trial u+(tau = 1) on the tentative direction.
+                n_cost++;
+                const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
+                                 + (GAMMA_L_COEFF / (2.0 * gamma)) * nr2;
+                if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
+                    f_back = true;                                       // (speculation discarded)
+                } else {
+                    sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                    if (state == D_LIP) {
+                        lb_first = false; osv = uv; osw = uw; ogv = rv; ogw = rw;     // first pair after a reset: only remembered
+                        if (iteration == 0) {
+                            // first iteration: plain forward-backward step; psi, grad psi at u_bar are at hand
+                            n_grad++;
+                            uv = hv; uw = hw;
+                            cost = psiA; gv = gAv; gw = gAw;
+                            NMPC_HALF_STEP(uv, uw);
+                            f_end = true;
+                        } else {
+                            dv = rv; dw = rw;                            // empty buffer: d = r
+                            rhs_ls = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane) - sigma * nr2;
+                            tau = 1.0; ls_n = 0;
+                            f_trials = true;
+                        }
+                    } else {
+                        lb_first = n_first; lb_head = n_head; lb_active = n_active; H0 = n_H0;      // commit
+                        if (n_take_old) { osv = uv; osw = uw; ogv = rv; ogw = rw; }
+                        n_grad++;
+                        qv = gv; qw = gw;                                // cache_previous_gradient
+                        cost = psiB; gv = gBv; gw = gBw;
+                        NMPC_HALF_STEP(pv, pw);
+                        const double lhs = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane);
+                        if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; }
+                        else { uv = pv; uw = pw; f_end = true; }
+                    }
+                }
+            } else if (state == D_LS) {
+                // half 0 evaluated trial (tau, ls_n), half 1 trial (tau/2, ls_n + 1)
+                double pAv, pBv, pAw, pBw;
+                both_halves(pv, pAv, pBv);
+                both_halves(pw, pAw, pBw);
+                n_grad++;
+                qv = gv; qw = gw;
+                cost = psiA; gv = gAv; gw = gAw;
+                pv = pAv; pw = pAw;
+                NMPC_HALF_STEP(pv, pw);
+                double lhs = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane);
+                bool accept = true;
+                if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) {
+                    tau /= 2.0; ls_n++;
+                    n_grad++;
+                    qv = gv; qw = gw;
+                    cost = psiB; gv = gBv; gw = gBw;
+                    pv = pBv; pw = pBw;
+                    NMPC_HALF_STEP(pv, pw);
+                    lhs = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane);
+                    if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; accept = false; }
+                }
+                if (accept) { uv = pv; uw = pw; f_end = true; }
+            } else {    // D_ALM: F1, F2 at the inner solution
+                n_cost++;
+                const double cbar_inv = 1.0 / fmax(pen_c, 1.0);
+                const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
+                ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
+                ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+                const double d1 = ypv - yv, d2 = ypw - yw;
+                dy_norm_plus = sqrt(group_sum<P>(in ? fma(d1, d1, d2 * d2) : 0.0, lane));
+                f2_norm_plus = sqrt(pen);
+                const double SMALL = DBL_EPSILON;
+                const bool crit1 = nu > 0 && __any(dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
+                const bool crit2 = a.n2 == 0 || __any(f2_norm_plus <= a.op.delta_tolerance + SMALL);
+                const bool crit3 = __any(eps_nu <= a.op.tolerance + SMALL);
+                if (crit1 && crit2 && crit3) {
+                    final_status = inner_status; running = false;
+                } else {
+                    const bool stall = nu == 0 || __any(dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
+                                                        f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
+                    if (!stall) pen_c *= a.op.penalty_update;
+                    eps_nu = fmax(a.op.tolerance_update * eps_nu, a.op.tolerance);
+                    yv = ypv; yw = ypw;
+                    dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
+                    nu++;
+                    if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
+                    else f_start = true;
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ results
+        if (in && h == 0) {
+            double *uo = a.u + (size_t)inst * a.n_u;
+            uo[2 * t] = uv; uo[2 * t + 1] = uw;
+            if (a.y_out) { a.y_out[(size_t)inst * a.n1 + t] = ypv; a.y_out[(size_t)inst * a.n1 + N + t] = ypw; }
+        }
+        if (lane == 0 && a.st) {
+            nmpc_status s;
+            s.exit_status = final_status;
+            s.num_outer_iterations = (uint32_t)(final_status == NMPC_NOT_CONVERGED_NOT_FINITE ? nu + 1 : (nu < a.op.max_outer ? nu + 1 : nu));
+            s.num_inner_iterations = inner_total;
+            s.num_cost_evals = n_cost;
+            s.num_grad_evals = n_grad;
+            s.reserved = 0;
+            s.last_problem_norm_fpr = last_fpr;
+            s.delta_y_norm_over_c = dy_norm_plus / pen_c;
+            s.f2_norm = f2_norm_plus;
+            s.penalty = pen_c;
+            s.cost = last_cost;
+            s.solve_time_ms = 0.0;
+            a.st[inst] = s;
+        }
+        NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
+    }
+}
+#undef NMPC_HALF_STEP
+
+}  // namespace nmpc
