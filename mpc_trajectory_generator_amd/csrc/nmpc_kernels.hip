@@ -68,6 +68,11 @@ struct KArgs {
 enum { SC_X0 = 0, SC_Y0, SC_TH0, SC_VINIT, SC_WINIT, SC_XF, SC_YF, SC_THF,
        SC_Q, SC_QV, SC_QTH, SC_RV, SC_RW, SC_QN, SC_QTHN, SC_QCTE, SC_PA, SC_PW };
 
+// LDS pointers carry their address space: no generic-pointer casts, always ds_* instructions
+typedef __attribute__((address_space(3))) double lds_double;
+typedef double dbl2 __attribute__((ext_vector_type(2)));     // (v, w) pair, 16-byte aligned
+typedef __attribute__((address_space(3))) dbl2 lds_double2;
+
 #define NMPC_WAVE_SYNC()                                           \
     do {                                                           \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
@@ -84,7 +89,7 @@ struct DynStage {
 // instance set-up: p -> LDS slice + per-lane registers     (reference mpc_generator.py:73-79,93-104,127-136)
 // ---------------------------------------------------------------------------------------------
 template <int P>
-__device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, const double *p, int t,
+__device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, const double *p, int t,
                                                  double &vref, DynStage &dyn)
 {
     const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
@@ -92,10 +97,11 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, cons
     if (t >= 8 && t < 18) L[a.map.sc + t] = p[t + 2];       // ten weights p[10:20]
     vref = t < N ? p[NZ + t] : 0.0;
     const double *ps = p + NZ + N;
-    for (int k = t; k < nobs; k += P) {
-        const double r = ps[3 * k + 2];
-        L[a.map.obs + 3 * k] = ps[3 * k];
-        L[a.map.obs + 3 * k + 1] = ps[3 * k + 1];
+    for (int k = t; k < ((nobs + 1) & ~1); k += P) {       // padded to an even count with an inert zero circle
+        const bool real = k < nobs;
+        const double r = real ? ps[3 * k + 2] : 0.0;
+        L[a.map.obs + 3 * k] = real ? ps[3 * k] : 0.0;
+        L[a.map.obs + 3 * k + 1] = real ? ps[3 * k + 1] : 0.0;
         L[a.map.obs + 3 * k + 2] = r * r;
     }
     const double *pd = ps + 3 * nobs;
@@ -113,11 +119,13 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, cons
         }
     }
     const double *pr = pd + 5 * ndyn * N;
-    if (t < N - 1) {
-        const double ax = pr[3 * t], ay = pr[3 * t + 1];
-        const double bx = pr[3 * t + 3], by = pr[3 * t + 4];
+    const int nseg4 = (N - 1 + 3) & ~3;                    // the CTE loop runs 4 segments per trip; the padding
+    if (t < nseg4) {                                       // repeats the last segment (cannot change a strict min)
+        const int i = t < N - 1 ? t : N - 2;
+        const double ax = pr[3 * i], ay = pr[3 * i + 1];
+        const double bx = pr[3 * i + 3], by = pr[3 * i + 4];
         const double dx = bx - ax, dy = by - ay;
-        double *sg = L + a.map.seg + SEG_STRIDE * t;
+        lds_double *sg = L + a.map.seg + SEG_STRIDE * t;
         sg[0] = ax;
         sg[1] = ay;
         sg[2] = dx;
@@ -131,15 +139,15 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, double *L, cons
 // psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); F2_k left in the LDS slice
 // ---------------------------------------------------------------------------------------------
 template <int P>
-__device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, int lane, int t, double zv, double zw,
-                                         double c, double yv, double yw, double vref, const DynStage &dyn,
+__device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
+                                         double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
                                          double &gw, double &av_out, double &aw_out)
 {
     const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
     const bool in = t < N;
-    const double *sc = L + a.map.sc;
+    const lds_double *sc = L + a.map.sc;
     const double x0 = sc[SC_X0], y0 = sc[SC_Y0], th0 = sc[SC_TH0];
     const double xf = sc[SC_XF], yf = sc[SC_YF], thf = sc[SC_THF];
 
@@ -153,7 +161,6 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, i
     const double xp = from_prev<P>(xn, lane, x0);
     const double yp = from_prev<P>(yn, lane, y0);
 
-    const double cbar_inv = 1.0 / fmax(c, 1.0);
     const double half_c = 0.5 * c;
 
     double acc = (sc[SC_RV] * zv) * zv;                                           // (:84)
@@ -169,15 +176,23 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, i
     double best = __builtin_inf();
     int bi = 0;
     {
-        const double *sg = L + a.map.seg;
-        for (int i = 0; i < N - 1; ++i, sg += SEG_STRIDE) {
-            const double px = xn - sg[0], py = yn - sg[1];
-            const double dot = fma(px, sg[2], py * sg[3]);
-            const double that = dot * sg[4];
-            const double tst = fmin(fmax(that, 0.0), 1.0);
-            const double ex = fma(tst, sg[2], -px), ey = fma(tst, sg[3], -py);
-            const double d2 = fma(ex, ex, ey * ey);
-            if (d2 < best) { best = d2; bi = i; }
+        const lds_double *sg = L + a.map.seg;
+        const int nseg4 = (N - 1 + 3) & ~3;
+        for (int i = 0; i < nseg4; i += 4, sg += 4 * SEG_STRIDE) {
+            double d2[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                   // four independent chains per trip
+                const lds_double *q = sg + j * SEG_STRIDE;
+                const double px = xn - q[0], py = yn - q[1];
+                const double dot = fma(px, q[2], py * q[3]);
+                const double that = dot * q[4];
+                const double tst = fmin(fmax(that, 0.0), 1.0);
+                const double ex = fma(tst, q[2], -px), ey = fma(tst, q[3], -py);
+                d2[j] = fma(ex, ex, ey * ey);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (d2[j] < best) { best = d2[j]; bi = i + j; }
         }
     }
     acc = fma(sc[SC_QCTE], best, acc);                                            // (:144)
@@ -208,18 +223,25 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, i
     unsigned long long act = 0ull;
     unsigned act_dyn = 0u;
     {
-        const double *ob = L + a.map.obs;
-        for (int k = 0; k < nobs; ++k, ob += 3) {
-            const double dx = xn - ob[0], dy = yn - ob[1];
-            const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));                   // (:112)
-            const double hm = in ? fmax(h, 0.0) : 0.0;
-            double f2 = 0.0;
-            if (__any(hm > 0.0)) {
-                act |= 1ull << k;
-                f2 = group_sum<P>(hm, lane);
-                pen = fma(f2, f2, pen);
-            }
+        const lds_double *ob = L + a.map.obs;
+        const int nobs2 = (nobs + 1) & ~1;
+        for (int k = 0; k < nobs2; k += 2, ob += 6) {       // activity scan, two circles per trip, no branches
+            const double dx0 = xn - ob[0], dy0 = yn - ob[1], dx1 = xn - ob[3], dy1 = yn - ob[4];
+            const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ob[2]));              // (:112)
+            const double h1 = fma(-dy1, dy1, fma(-dx1, dx1, ob[5]));
+            const unsigned long long b0 = __ballot(in && h0 > 0.0), b1 = __ballot(in && h1 > 0.0);
+            act |= (unsigned long long)(b0 != 0) << k;
+            act |= (unsigned long long)(b1 != 0) << (k + 1);
+        }
+        for (unsigned long long rem = act; rem;) {
+            const int k = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            const lds_double *o1 = L + a.map.obs + 3 * k;
+            const double dx = xn - o1[0], dy = yn - o1[1];
+            const double h = fma(-dy, dy, fma(-dx, dx, o1[2]));
+            const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
             if (t == 0) L[f2off + k] = f2;
+            pen = fma(f2, f2, pen);
         }
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
@@ -229,13 +251,12 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, i
                 const double eb = fma(dx, dyn.sa[k], -(dy * dyn.ca[k]));
                 const double h = fma(-(eb * eb), dyn.iry2[k], fma(-(ea * ea), dyn.irx2[k], 1.0));   // (:118)
                 const double hm = in ? fmax(h, 0.0) : 0.0;
-                double f2 = 0.0;
                 if (__any(hm > 0.0)) {
                     act_dyn |= 1u << k;
-                    f2 = group_sum<P>(hm, lane);
+                    const double f2 = group_sum<P>(hm, lane);
+                    if (t == 0) L[f2off + nobs + k] = f2;
                     pen = fma(f2, f2, pen);
                 }
-                if (t == 0) L[f2off + nobs + k] = f2;
             }
         }
     }
@@ -247,7 +268,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, i
     // ---- adjoint sweep (what CasADi reverse AD generated for the reference) ----
     double gx, gy;
     {
-        const double *sg = L + a.map.seg + SEG_STRIDE * bi;          // arg-min segment of this stage
+        const lds_double *sg = L + a.map.seg + SEG_STRIDE * bi;          // arg-min segment of this stage
         const double px = xn - sg[0], py = yn - sg[1];
         const double dot = fma(px, sg[2], py * sg[3]);
         const double that = dot * sg[4];
@@ -260,11 +281,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, double *L, int f2off, i
         gy = two_q * fma(m, sg[3], -ey);
     }
     {
-        const double *f2 = L + f2off;
+        const lds_double *f2 = L + f2off;
         while (act) {                                        // only the circles some stage is inside of
             const int k = __builtin_ctzll(act);
             act &= act - 1;
-            const double *ob = L + a.map.obs + 3 * k;
+            const lds_double *ob = L + a.map.obs + 3 * k;
             const double wk = -2.0 * (c * f2[k]);
             const double dx = xn - ob[0], dy = yn - ob[1];
             const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));
@@ -330,7 +351,7 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
     extern __shared__ double lds[];
     constexpr int K = 64 / P;
     const int lane = threadIdx.x, g = lane / P, t = lane % P;
-    double *L = lds + g * a.map.total;
+    lds_double *L = (lds_double *)lds + g * a.map.total;
     const int N = a.pb.N;
     const int inst = blockIdx.x * K + g;
     const int b = inst < a.B ? inst : a.B - 1;          // surplus groups redo the last instance, write nothing
@@ -342,8 +363,10 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
     const double c = a.ev_c ? a.ev_c[b] : 0.0;
     const double yv = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + t] : 0.0;
     const double yw = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + N + t] : 0.0;
+    for (int k = t; k < a.n2; k += P) L[a.map.f2 + k] = 0.0;
+    NMPC_WAVE_SYNC();
     double psi, pen, gv, gw, av, aw;
-    eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, c, yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
+    eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, c, 1.0 / fmax(c, 1.0), yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
     if (inst >= a.B) return;
     if (t == 0 && a.ev_psi) a.ev_psi[b] = psi;
     if (t < N) {
@@ -364,12 +387,12 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     extern __shared__ double lds[];
     const int lane = threadIdx.x, g = lane / P, t = lane % P;
     const int gbase = g * P;
-    double *L = lds + g * a.map.total;
+    lds_double *L = (lds_double *)lds + g * a.map.total;
     const int N = a.pb.N, m = a.op.lbfgs_memory;
     const bool in = t < N;
-    double2 *LS = reinterpret_cast<double2 *>(L + a.map.S);
-    double2 *LY = reinterpret_cast<double2 *>(L + a.map.Y);
-    double *Lrho = L + a.map.rho;
+    lds_double2 *LS = (lds_double2 *)(L + a.map.S);
+    lds_double2 *LY = (lds_double2 *)(L + a.map.Y);
+    lds_double *Lrho = L + a.map.rho;
 
     // ---- per-group state (every lane of a group holds the same control values) ----
     int state = ST_IDLE, inst = -1;
@@ -431,7 +454,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
         // ------------------------------------------------------------------ one evaluation of psi per group
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         const bool wg = __any(live && need_grad);
-        eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, pen_c, yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
+        eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
         if (!live) continue;
 
         // ------------------------------------------------------------------ consume it
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                     if (ok) {
                         osv = uv; osw = uw; ogv = rv; ogw = rw;
                         lb_head = lb_head == 0 ? m - 1 : lb_head - 1;
-                        if (in) { LS[lb_head * N + t] = make_double2(s1, s2); LY[lb_head * N + t] = make_double2(y1, y2); }
+                        if (in) { LS[lb_head * N + t] = dbl2{s1, s2}; LY[lb_head * N + t] = dbl2{y1, y2}; }
                         if (t == 0) Lrho[lb_head] = 1.0 / ys;
                         H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
                         if (lb_active < m) lb_active++;
@@ -515,8 +538,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                         alpha[k] = 0.0;
                         if (k < lb_active) {
                             int slot = lb_head + k; if (slot >= m) slot -= m;
-                            const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
-                            const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
+                            const dbl2 s = in ? LS[slot * N + t] : dbl2{0.0, 0.0};
+                            const dbl2 y = in ? LY[slot * N + t] : dbl2{0.0, 0.0};
                             const double al = Lrho[slot] * hdot<P>(s.x, s.y, dv, dw, lane);
                             alpha[k] = al;
                             dv = fma(-al, y.x, dv); dw = fma(-al, y.y, dw);
@@ -527,8 +550,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                     for (int k = MAXMEM - 1; k >= 0; --k) {
                         if (k < lb_active) {
                             int slot = lb_head + k; if (slot >= m) slot -= m;
-                            const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
-                            const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
+                            const dbl2 s = in ? LS[slot * N + t] : dbl2{0.0, 0.0};
+                            const dbl2 y = in ? LY[slot * N + t] : dbl2{0.0, 0.0};
                             const double be = Lrho[slot] * hdot<P>(y.x, y.y, dv, dw, lane);
                             const double ab = alpha[k] - be;
                             dv = fma(ab, s.x, dv); dw = fma(ab, s.y, dw);
@@ -737,8 +760,8 @@ static LdsMap make_map(const nmpc_problem &pb, int m)
     LdsMap mp;
     int o = 0;
     mp.sc = o;  o += 20;
-    mp.seg = o; o += nmpc::SEG_STRIDE * pb.N;
-    mp.obs = o; o += 3 * (pb.nobs > 0 ? pb.nobs : 1);
+    mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 3);
+    mp.obs = o; o += 3 * (pb.nobs + 2);
     mp.f2 = o;  o += 2 * (pb.nobs + pb.ndyn + 1);     // one F2 array per half (dual kernel)
     mp.rho = o; o += m;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays

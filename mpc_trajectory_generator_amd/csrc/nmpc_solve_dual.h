@@ -28,6 +28,14 @@ __device__ __forceinline__ void both_halves(double v, double &from_h0, double &f
 
 enum : int { D_INIT = 0, D_LIP, D_ITER, D_LS, D_ALM };
 
+// unconditional LDS load of a (v, w) pair, zeroed for lanes beyond the horizon
+__device__ __forceinline__ dbl2 ld_pair(const lds_double2 *base, int idx, bool keep)
+{
+    dbl2 v = base[idx];
+    if (!keep) { v.x = 0.0; v.y = 0.0; }
+    return v;
+}
+
 // forward-backward envelope at the point whose cost / gradient / gradient step / half step are given
 template <int P>
 __device__ __forceinline__ double fbe_value(double cost, double gamma, double sv, double sw, double hv, double hw,
@@ -51,14 +59,14 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
 {
     constexpr int P = 32;
     extern __shared__ double lds[];
-    double *L = lds;
+    lds_double *L = (lds_double *)lds;
     const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
     const int N = a.pb.N, m = a.op.lbfgs_memory;
     const bool in = t < N;
     const int f2off = a.map.f2 + h * (a.n2 + 1);
-    double2 *LS = reinterpret_cast<double2 *>(L + a.map.S);
-    double2 *LY = reinterpret_cast<double2 *>(L + a.map.Y);
-    double *Lrho = L + a.map.rho;
+    lds_double2 *LS = (lds_double2 *)(L + a.map.S);
+    lds_double2 *LY = (lds_double2 *)(L + a.map.Y);
+    lds_double *Lrho = L + a.map.rho;
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
 
@@ -96,14 +104,21 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         unsigned num_iter = 0;
         const double c0 = a.c0 ? a.c0[inst] : 0.0;
         double pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
+        double cbar_inv = 1.0 / fmax(pen_c, 1.0);          // 1 / max(c, 1), refreshed when c changes
+        double c_lip = 0;                                   // 0.95 / (2 gamma), refreshed when gamma changes
         double eps_nu = a.op.initial_tolerance;
         double dy_norm = 0, f2_norm = 0, dy_norm_plus = DBL_MAX, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
-        unsigned inner_total = 0, n_cost = 0, n_grad = 0;
+        unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
         bool running = true;
+#ifdef NMPC_PROFILE
+        long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
+#define NMPC_TICK(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
+        NMPC_TICK(tk0);
+#endif
 
         for (;;) {
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
@@ -111,6 +126,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 f_back = false;
                 lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
                 Lc *= 2.0; gamma /= 2.0;
+                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
                 nr2 = hdot<P>(rv, rw, rv, rw, lane);
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                         if (__any(ok)) {
                             n_take_old = true;
                             n_head = lb_head == 0 ? m - 1 : lb_head - 1;
-                            if (in && h == 0) { LS[n_head * N + t] = make_double2(s1, s2); LY[n_head * N + t] = make_double2(y1, y2); }
+                            if (in && h == 0) { LS[n_head * N + t] = dbl2{s1, s2}; LY[n_head * N + t] = dbl2{y1, y2}; }
                             if (lane == 0) Lrho[n_head] = 1.0 / ys;
                             n_H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
                             if (n_active < m) n_active++;
@@ -175,35 +192,49 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     }
                     // ---- d = H r, two-loop recursion over the tentative buffer ----
                     dv = rv; dw = rw;
-                    {
+                    if (n_active > 0) {
+                        // pair k lives in ring slot (n_head + k) mod m; each trip fetches the NEXT pair from
+                        // LDS before it reduces the current one, so the LDS latency hides under the reduction
                         double alpha[MAXMEM];
+                                                const int tt = in ? t : 0;               // lanes beyond the horizon read lane 0's pair and drop it
+                        int slot = n_head;
+                        dbl2 sc_ = ld_pair(LS, slot * N + tt, in), yc_ = ld_pair(LY, slot * N + tt, in);
+                        double rc_ = Lrho[slot];
 #pragma unroll
                         for (int k = 0; k < MAXMEM; ++k) {
                             alpha[k] = 0.0;
                             if (k < n_active) {
-                                int slot = n_head + k; if (slot >= m) slot -= m;
-                                const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
-                                const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
-                                const double al = Lrho[slot] * hdot<P>(s.x, s.y, dv, dw, lane);
+                                dbl2 sn_ = {0.0, 0.0}, yn_ = {0.0, 0.0};
+                                double rn_ = 0.0;
+                                if (k + 1 < n_active) {
+                                    slot = slot + 1 == m ? 0 : slot + 1;
+                                    sn_ = ld_pair(LS, slot * N + tt, in); yn_ = ld_pair(LY, slot * N + tt, in); rn_ = Lrho[slot];
+                                }
+                                const double al = rc_ * hdot<P>(sc_.x, sc_.y, dv, dw, lane);
                                 alpha[k] = al;
-                                dv = fma(-al, y.x, dv); dw = fma(-al, y.y, dw);
+                                dv = fma(-al, yc_.x, dv); dw = fma(-al, yc_.y, dw);
+                                if (k + 1 < n_active) { sc_ = sn_; yc_ = yn_; rc_ = rn_; }
                             }
                         }
-                        if (n_active > 0) { dv = n_H0 * dv; dw = n_H0 * dw; }
+                        dv = n_H0 * dv; dw = n_H0 * dw;
+                        // (sc_, yc_, rc_) now hold the oldest pair, k = n_active - 1; walk back to the newest
 #pragma unroll
                         for (int k = MAXMEM - 1; k >= 0; --k) {
                             if (k < n_active) {
-                                int slot = n_head + k; if (slot >= m) slot -= m;
-                                const double2 s = in ? LS[slot * N + t] : make_double2(0.0, 0.0);
-                                const double2 y = in ? LY[slot * N + t] : make_double2(0.0, 0.0);
-                                const double be = Lrho[slot] * hdot<P>(y.x, y.y, dv, dw, lane);
+                                dbl2 sn_ = {0.0, 0.0}, yn_ = {0.0, 0.0};
+                                double rn_ = 0.0;
+                                if (k > 0) {
+                                    slot = slot == 0 ? m - 1 : slot - 1;
+                                    sn_ = ld_pair(LS, slot * N + tt, in); yn_ = ld_pair(LY, slot * N + tt, in); rn_ = Lrho[slot];
+                                }
+                                const double be = rc_ * hdot<P>(yc_.x, yc_.y, dv, dw, lane);
                                 const double ab = alpha[k] - be;
-                                dv = fma(ab, s.x, dv); dw = fma(ab, s.y, dw);
+                                dv = fma(ab, sc_.x, dv); dw = fma(ab, sc_.y, dw);
+                                if (k > 0) { sc_ = sn_; yc_ = yn_; rc_ = rn_; }
                             }
                         }
                     }
-                    const double sg = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-                    rhs_ls = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane) - sg * nr2;
+                    rhs_ls = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane) - sigma * nr2;
                     tau = 1.0; ls_n = 0;
                     const double omt = 1.0 - tau;
                     pv = fma(-tau, dv, fma(-omt, rv, uv));
@@ -240,7 +271,15 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
 
             // ================================================================ one pass: psi at two points
             double psi, pen, egv = 0, egw = 0, eav, eaw;
-            eval_psi<P>(a, L, f2off, lane, t, zv, zw, pen_c, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+            n_pass++;
+#ifdef NMPC_PROFILE
+            NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
+#endif
+            eval_psi<P>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+#ifdef NMPC_PROFILE
+            { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
+            NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
+#endif
             double psiA, psiB, gAv, gBv, gAw, gBw;
             both_halves(psi, psiA, psiB);
             both_halves(egv, gAv, gBv);
@@ -253,6 +292,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / norm_h;
                 gamma = GAMMA_L_COEFF / fmax(Lc, MIN_LIPSCHITZ_CONSTANT);
                 sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
                 f_begin = true;
             } else if (state == D_LIP || state == D_ITER) {
@@ -261,11 +301,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 // speculative trial u+(tau = 1) on the tentative direction.
                 n_cost++;
                 const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
-                                 + (GAMMA_L_COEFF / (2.0 * gamma)) * nr2;
+                                 + c_lip * nr2;
                 if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
                     f_back = true;                                       // (speculation discarded)
                 } else {
-                    sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                     if (state == D_LIP) {
                         lb_first = false; osv = uv; osw = uw; ogv = rv; ogw = rw;     // first pair after a reset: only remembered
                         if (iteration == 0) {
@@ -318,7 +357,6 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 if (accept) { uv = pv; uw = pw; f_end = true; }
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
-                const double cbar_inv = 1.0 / fmax(pen_c, 1.0);
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
                 ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
                 ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
@@ -334,7 +372,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 } else {
                     const bool stall = nu == 0 || __any(dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
                                                         f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
-                    if (!stall) pen_c *= a.op.penalty_update;
+                    if (!stall) { pen_c *= a.op.penalty_update; cbar_inv = 1.0 / fmax(pen_c, 1.0); }
                     eps_nu = fmax(a.op.tolerance_update * eps_nu, a.op.tolerance);
                     yv = ypv; yw = ypw;
                     dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
@@ -343,6 +381,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     else f_start = true;
                 }
             }
+#ifdef NMPC_PROFILE
+            { double keep = uv + gv + hv + cost; asm volatile("" : "+v"(keep)); }
+            NMPC_TICK(tk1); cyc_post += tk1 - tk0; tk0 = tk1;
+#endif
         }
 
         // ------------------------------------------------------------------ results
@@ -358,13 +400,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
             s.num_inner_iterations = inner_total;
             s.num_cost_evals = n_cost;
             s.num_grad_evals = n_grad;
-            s.reserved = 0;
+            s.reserved = n_pass;                 // evaluation passes actually executed (diagnostic)
             s.last_problem_norm_fpr = last_fpr;
             s.delta_y_norm_over_c = dy_norm_plus / pen_c;
             s.f2_norm = f2_norm_plus;
             s.penalty = pen_c;
             s.cost = last_cost;
             s.solve_time_ms = 0.0;
+#ifdef NMPC_PROFILE
+            s.last_problem_norm_fpr = (double)cyc_eval; s.delta_y_norm_over_c = (double)cyc_top; s.f2_norm = (double)cyc_post;
+#endif
             a.st[inst] = s;
         }
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
