@@ -1,0 +1,196 @@
+"""Receding-horizon drivers on top of the solver handle.
+
+``TrajectoryGenerator.run`` follows the reference's ``PathGenerator.run`` loop
+(src/path_generator.py:197-437) call for call -- manager start / ping, per-step parameter
+assembly, ``mpc_step`` (= ``MpcModule.run``, src/mpc/mpc_generator.py:204-237), terminal test, kill
+-- so a user of the reference finds the same control flow, with the OpEn TCP manager replaced by
+``tcp_shim.OptimizerTcpManager``.  The visibility-graph A* front-end (extremitypathfinder /
+pyclipper) is outside this project's scope; a ``harness.Route`` (waypoints + NMPC vertices) is
+what ``run`` starts from.
+
+``BatchedRecedingHorizon`` is the batched counterpart for BASELINE config 4: B independent robots
+advance in lock step, one batched solve per step, controls and multipliers carried as warm starts.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+
+from . import harness
+from .config import Config
+from .tcp_shim import OptimizerTcpManager
+
+
+def mpc_step(cfg: Config, parameters, mng, take_steps, system_input, states):
+    """One NMPC solve + state advance: src/mpc/mpc_generator.py:204-237."""
+    solution = mng.call(parameters)                                          # :206
+    if solution.is_ok():                                                     # :209-214
+        data = solution.get()
+        u, exit_status, solver_time = data.solution, data.exit_status, data.solve_time_ms
+    else:                                                                    # :215-221
+        err = solution.get()
+        mng.kill()
+        raise RuntimeError(f"MPC Solver error: {err.message}")
+    system_input += u[:cfg.nu * take_steps]                                  # :223
+    for i in range(take_steps):                                              # :225-235, Euler diff-drive
+        u_v, u_omega = u[i * cfg.nu], u[1 + i * cfg.nu]
+        x, y, theta = states[-3], states[-2], states[-1]
+        states += [x + cfg.ts * (u_v * math.cos(theta)), y + cfg.ts * (u_v * math.sin(theta)),
+                   theta + cfg.ts * u_omega]
+    return exit_status, solver_time
+
+
+class TrajectoryGenerator:
+    """Counterpart of the reference's ``PathGenerator`` (plots and reports omitted)."""
+
+    def __init__(self, config: Config, build: bool = False, verbose: bool = False, sinus_object: bool = False,
+                 manager_factory=None):
+        self.config, self.verbose, self.sinus_object = config, verbose, sinus_object
+        self.time_dict, self.solver_times, self.overhead_times = {}, [], []
+        self._factory = manager_factory or (lambda: OptimizerTcpManager(
+            config.build_directory + "/" + config.optimizer_name, config=config))
+        # build=True triggers OpEn code generation in the reference (:33-34); here the kernels are
+        # compiled when the library is first loaded, nothing to do.
+
+    def run(self, route: harness.Route, max_steps: int | None = None, record_parameters: list | None = None):
+        """-> (xx, xy, uv, uomega, solver_times, overhead_times), src/path_generator.py:197-437."""
+        cfg = self.config
+        t_temp = time.time()
+        mng = self._factory()                                                 # :218-222
+        mng.start()
+        mng.ping()
+        self.time_dict["opt_launch"] = int(1000 * (time.time() - t_temp))
+        tt = time.time()
+        start, end = list(route.start), list(route.end)
+        x_ref, y_ref = route.x_ref, route.y_ref
+        terminal, t, idx = False, 0, 0
+        self.solver_times, self.overhead_times = [], []
+        system_input = []
+        states = list(map(float, start))                                      # :267
+        constraints = [0.0] * cfg.Nobs * cfg.nobs                             # :273
+        dyn_constraints = harness.initial_dyn_constraints(cfg)                # :274-280
+        params_per_dyn_obs = cfg.N_hor * cfg.ndynobs
+        limit = 500.0 / cfg.ts if max_steps is None else max_steps
+        t_temp = time.time()
+        while (not terminal) and t < limit:                                   # :290
+            t_overhead = time.time()
+            x_init = states[-cfg.nx:]                                         # :293
+            if len(route.vertices):                                           # :295-304
+                constraints = harness.static_constraints(route, (x_init[0], x_init[1]))
+            if t == 0:                                                        # :306-309
+                for i, obs in enumerate(harness.dyn_obstacle(cfg, route.dyn_obs_list, t * cfg.ts, cfg.N_hor,
+                                                             self.sinus_object)):
+                    dyn_constraints[i * params_per_dyn_obs:(i + 1) * params_per_dyn_obs] = \
+                        [float(v) for tup in obs for v in tup]
+            else:                                                             # :310-316 rotate left, refresh the tail
+                k = cfg.ndynobs * cfg.num_steps_taken
+                dyn_constraints = dyn_constraints[k:] + dyn_constraints[:k]
+                for i, obs in enumerate(harness.dyn_obstacle(cfg, route.dyn_obs_list,
+                                                             (t + cfg.N_hor - cfg.num_steps_taken) * cfg.ts,
+                                                             cfg.num_steps_taken, self.sinus_object)):
+                    dyn_constraints[(i + 1) * params_per_dyn_obs - k:(i + 1) * params_per_dyn_obs] = \
+                        [float(v) for tup in obs for v in tup]
+            lb_idx = max(0, idx - 1 * cfg.num_steps_taken)                    # :320-325
+            ub_idx = min(len(x_ref), idx + 5 * cfg.num_steps_taken)
+            idx = harness.closest_index((x_init[0], x_init[1]), route.ref_points[lb_idx:ub_idx]) + lb_idx
+            last_u = system_input[-cfg.nu:] if len(system_input) else [0.0] * cfg.nu     # :371-374
+            parameters = harness.assemble_params(route, x_init, last_u, idx, constraints, dyn_constraints)
+            if record_parameters is not None:
+                record_parameters.append(list(parameters))
+            try:                                                              # :384-391
+                exit_status, solver_time = mpc_step(cfg, parameters, mng, cfg.num_steps_taken, system_input, states)
+                self.solver_times.append(solver_time)
+            except RuntimeError as err:
+                if self.verbose:
+                    print(err)
+                return None
+            if exit_status in cfg.bad_exit_codes and self.verbose:            # :393-394
+                print(f"[MPC] Bad converge status: {exit_status}")
+            if np.allclose(states[-3:-1], end[0:2], atol=0.05, rtol=0) and abs(system_input[-2]) < 0.005:   # :397
+                terminal = True
+            t += cfg.num_steps_taken
+            self.overhead_times.append((time.time() - t_overhead) * 1000.0 - solver_time)
+        mng.kill()                                                            # :417
+        self.time_dict["mpc_time"] = int(1000 * (time.time() - t_temp))
+        self.time_dict["solver_time"] = sum(self.solver_times)
+        self.time_dict["mean_solver_time"] = float(np.mean(self.solver_times)) if self.solver_times else 0.0
+        self.time_dict["total_time"] = int(1000 * (time.time() - tt))
+        nx = cfg.nx
+        return (states[0::nx], states[1::nx], system_input[0::2], system_input[1::2],
+                self.solver_times, self.overhead_times)
+
+
+class BatchedRecedingHorizon:
+    """B robots on one route, advanced in lock step with one batched solve per step.
+
+    Per robot and step the parameter vector is filled as ``TrajectoryGenerator.run`` does
+    (closest reference sample in the sliding window, horizon padded with the end pose, braking
+    ``vel_ref``, dynamic block rotated left and refreshed).  ``solve_fn(P, u0, y0) -> (U, Y, status)``
+    is the batched solver (``BatchSolver.solve``); controls and multipliers are carried over as
+    warm starts, the penalty restarts at its initial value, like the sequential path.
+    """
+
+    def __init__(self, route: harness.Route, starts, dyn_obs_lists=None, sinus_object=False):
+        self.route, self.cfg = route, route.cfg
+        self.B = len(starts)
+        self.states = [list(map(float, s)) for s in starts]       # per robot: flat [x, y, theta, ...]
+        self.inputs = [[] for _ in range(self.B)]
+        self.idx = [0] * self.B
+        self.t = 0
+        self.dyn_lists = dyn_obs_lists if dyn_obs_lists is not None else [route.dyn_obs_list] * self.B
+        self.sinus_object = sinus_object
+        self.dyn = [harness.initial_dyn_constraints(self.cfg) for _ in range(self.B)]
+        self.constraints = [[0.0] * self.cfg.Nobs * self.cfg.nobs for _ in range(self.B)]
+        self.U = np.zeros((self.B, self.cfg.n_u))
+        self.Y = np.zeros((self.B, self.cfg.n1))
+        self.done = np.zeros(self.B, dtype=bool)
+
+    def assemble(self):
+        cfg, route = self.cfg, self.route
+        per = cfg.N_hor * cfg.ndynobs
+        k = cfg.ndynobs * cfg.num_steps_taken
+        P = np.empty((self.B, cfg.n_p))
+        for b in range(self.B):
+            x_init = self.states[b][-cfg.nx:]
+            if len(route.vertices):
+                self.constraints[b] = harness.static_constraints(route, (x_init[0], x_init[1]))
+            if self.t == 0:
+                preds = harness.dyn_obstacle(cfg, self.dyn_lists[b], 0.0, cfg.N_hor, self.sinus_object)
+                for i, obs in enumerate(preds):
+                    self.dyn[b][i * per:(i + 1) * per] = [float(v) for tup in obs for v in tup]
+            else:
+                self.dyn[b] = self.dyn[b][k:] + self.dyn[b][:k]
+                preds = harness.dyn_obstacle(cfg, self.dyn_lists[b], (self.t + cfg.N_hor - cfg.num_steps_taken) * cfg.ts,
+                                             cfg.num_steps_taken, self.sinus_object)
+                for i, obs in enumerate(preds):
+                    self.dyn[b][(i + 1) * per - k:(i + 1) * per] = [float(v) for tup in obs for v in tup]
+            lb = max(0, self.idx[b] - cfg.num_steps_taken)
+            ub = min(len(route.x_ref), self.idx[b] + 5 * cfg.num_steps_taken)
+            self.idx[b] = harness.closest_index((x_init[0], x_init[1]), route.ref_points[lb:ub]) + lb
+            last_u = self.inputs[b][-cfg.nu:] if self.inputs[b] else [0.0] * cfg.nu
+            P[b] = harness.assemble_params(route, x_init, last_u, self.idx[b], self.constraints[b], self.dyn[b])
+        return P
+
+    def advance(self, U):
+        cfg = self.cfg
+        for b in range(self.B):
+            u = U[b]
+            self.inputs[b] += [float(v) for v in u[:cfg.nu * cfg.num_steps_taken]]
+            st = self.states[b]
+            for i in range(cfg.num_steps_taken):
+                x, y, th = st[-3], st[-2], st[-1]
+                st += [x + cfg.ts * (u[i * cfg.nu] * math.cos(th)), y + cfg.ts * (u[i * cfg.nu] * math.sin(th)),
+                       th + cfg.ts * u[1 + i * cfg.nu]]
+            end = self.route.end
+            self.done[b] = (abs(st[-3] - end[0]) <= 0.05 and abs(st[-2] - end[1]) <= 0.05
+                            and abs(self.inputs[b][-2]) < 0.005)
+        self.t += cfg.num_steps_taken
+
+    def step(self, solve_fn):
+        P = self.assemble()
+        U, Y, st = solve_fn(P, self.U, self.Y)
+        self.U, self.Y = U, Y
+        self.advance(U)
+        return P, st

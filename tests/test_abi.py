@@ -53,4 +53,6 @@ def test_product_does_not_import_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in text and "from oracle" not in text and "nmpc_oracle" not in text, f
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
+                assert not re.search(r"#\s*include[^\n]*oracle", text), f
+                assert "libnmpc_oracle" not in text and "dlopen" not in text, f

@@ -151,3 +151,52 @@ def test_full_size_batch_properties(solvers):
     assert np.array_equal(u[idx], uo) and np.array_equal(y[idx], yo)
     for f in STATUS_FIELDS:
         assert np.array_equal(st[f][idx], sto[f]), f
+
+
+def test_tcp_shim_sequential_semantics():
+    """OptimizerTcpManager-shaped handle: warm start carried by the manager, OpEn error codes."""
+    from mpc_trajectory_generator_amd.tcp_shim import OptimizerTcpManager
+    cfg = named_config("cfg1")
+    o = oracle_for(cfg)
+    P = synthetic_batch(cfg, 1, 3, 11)
+    mng = OptimizerTcpManager("mpc_build/navigation", config=cfg, max_batch=8)
+    with pytest.raises(ConnectionRefusedError):
+        mng.call(list(P[0]))
+    mng.start()
+    assert mng.ping() == {"Pong": 1}
+    u_prev, y_prev = np.zeros((1, cfg.n_u)), np.zeros((1, cfg.n1))
+    for k in range(3):
+        r = mng.call(list(P[k]))
+        assert r.is_ok()
+        s = r.get()
+        uo, yo, sto = o.solve_batch(P[k:k + 1], u0=u_prev, y0=y_prev)          # previous solution / multipliers persist
+        assert s.solution == list(uo[0]) and s.lagrange_multipliers == list(yo[0])
+        assert s.exit_status in ("Converged", "NotConvergedIterations")
+        assert s.num_inner_iterations == sto["num_inner_iterations"][0] and s.solve_time_ms > 0
+        u_prev, y_prev = uo, yo
+    bad = mng.call(list(P[0][:-1]))
+    assert not bad.is_ok() and bad.get().code == 3003
+    assert mng.call(list(P[0]), initial_guess=[0.0] * 3).get().code == 1600
+    assert mng.call(list(P[0]), initial_y=[0.0] * 3).get().code == 1700
+    r = mng.call(list(P[0]), initial_guess=[0.0] * cfg.n_u, initial_y=[0.0] * cfg.n1, initial_penalty=5.0)
+    uo, yo, sto = o.solve_batch(P[0:1], c0=np.array([5.0]))
+    assert r.get().solution == list(uo[0])
+    mng.kill()
+    with pytest.raises(ConnectionRefusedError):
+        mng.ping()
+
+
+def test_closed_loop_scene1_reaches_goal():
+    """BASELINE config 0 through the HIP path: default.yaml, scene 1, closed loop to the goal."""
+    from mpc_trajectory_generator_amd import harness
+    from mpc_trajectory_generator_amd.trajectory import TrajectoryGenerator
+    cfg = named_config("cfg1")
+    route = harness.scene_route(cfg, 1)
+    xx, xy, uv, uw, solver_times, overhead = TrajectoryGenerator(cfg).run(route)
+    assert abs(xx[-1] - 19.0) <= 0.05 and abs(xy[-1] - 10.0) <= 0.05 and abs(uv[-1]) < 0.005
+    assert len(solver_times) == len(uv) < 400
+    # clearance from the three NMPC vertices of the scene (circle radius 0.5, soft constraint)
+    for vx, vy in route.vertices:
+        assert np.min(np.hypot(np.array(xx) - vx, np.array(xy) - vy)) > 0.45
+    d = np.load("tests/golden/harness_scene1.npz")       # the reference's loop with the oracle as its solver
+    assert np.array_equal(xx, d["xx"]) and np.array_equal(xy, d["xy"])

@@ -1,0 +1,146 @@
+"""CPU: host-side harness (reference path, braking tables, obstacle selection, parameter assembly and
+the receding-horizon driver) against goldens captured by running the reference's own
+PathGenerator.run / MpcModule.run / PathPreProcessor under stubs (tests/golden/make_harness_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from mpc_trajectory_generator_amd import load_config, named_config
+from mpc_trajectory_generator_amd import harness
+from mpc_trajectory_generator_amd.trajectory import BatchedRecedingHorizon, TrajectoryGenerator
+
+
+class ReplayManager:
+    """Hands back the solutions the reference run received, in order, and checks nothing else."""
+
+    def __init__(self, solutions, exits):
+        self.solutions, self.exits, self.k, self.alive = solutions, exits, 0, False
+
+    def start(self):
+        self.alive = True
+
+    def ping(self):
+        assert self.alive
+        return {"Pong": 1}
+
+    def kill(self):
+        self.alive = False
+
+    def call(self, p):
+        from mpc_trajectory_generator_amd.tcp_shim import SolverResponse
+
+        class S:
+            pass
+        if self.k >= len(self.solutions):
+            raise KeyboardInterrupt
+        s = S()
+        s.solution = [float(v) for v in self.solutions[self.k]]
+        s.exit_status = ("Converged", "NotConvergedIterations")[int(self.exits[self.k])]
+        s.solve_time_ms = 1.0
+        self.k += 1
+        r = SolverResponse.__new__(SolverResponse)
+        r._payload = s
+        r.is_ok = lambda: True
+        return r
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_rough_ref_and_brake_tables_scene1():
+    d, cfg = load("harness_scene1.npz"), named_config("default")
+    x, y, th = harness.rough_ref(cfg, d["start"][:2], [tuple(p) for p in d["path"][1:]])
+    assert np.array_equal(x, d["x_ref"]) and np.array_equal(y, d["y_ref"]) and np.array_equal(th, d["theta_ref"])
+    bv, bd = harness.brake_vel_ref(cfg)
+    assert np.array_equal(bv, d["brake_vel"]) and np.array_equal(bd, d["brake_dist"])
+    # SURVEY.md Appendix F anchors
+    assert bv[:3] == [1.5, 1.4210526315789473, 1.3421052631578947] and bd[:3] == [3.0, 2.7, 2.4157894736842107]
+    x, y, th = harness.rough_ref(cfg, (1, 1), [(4, 1), (4, 3)])
+    assert len(x) == 16 and abs(x[0] - 1.33) < 1e-12 and (x[-1], y[-1]) == (4.0, 3.0) and th[-1] == math.pi / 2
+    with pytest.raises(ValueError):
+        harness.rough_ref(cfg, (1, 1), [(1, 1), (2, 2)])         # reference: NameError
+
+
+def test_dyn_obstacle_and_vertex_selection_scene12():
+    d = load("harness_scene12.npz")
+    cfg = load_config(num_steps_taken=2, Nobs=4)
+    obs = [[[o[0], o[1]], [o[2], o[3]], o[4], o[5], o[6], o[7]] for o in d["dyn_obs"]]
+    pred = np.array(harness.dyn_obstacle(cfg, obs, 1.4, 20, True))
+    np.testing.assert_allclose(pred, d["dyn_pred_t1p4_h20"], rtol=0, atol=1e-12)
+    pred1 = np.array(harness.dyn_obstacle(cfg, obs, 3.0, 1, False))
+    np.testing.assert_allclose(pred1, d["dyn_pred_t3_h1"], rtol=0, atol=1e-12)
+    # linspace spacing quirk: horizon*ts/(horizon-1), not ts
+    p0 = harness.dyn_obstacle(cfg, obs, 0.0, 20)
+    assert p0[0][0][:2] == (28.1, 18.2) and abs(p0[0][1][0] - 27.978740066806175) < 1e-12
+    vert = [tuple(v) for v in d["vertices"]]
+    for n, lb, key in ((4, 0, "fcv"), (5, 2, "fcv2")):
+        for j, pos in enumerate([(19.0, 7.0), (22.5, 18.0), (30.0, 26.0), (44.0, 8.0)]):
+            got = harness.find_closest_vertices(vert, pos, n, lb)
+            assert len(got) == d[key + "_len"][j]
+            if got:
+                assert tuple(got[0]) == tuple(d[key + "_first"][j])
+
+
+@pytest.mark.parametrize("name,over,sinus", [("harness_scene1.npz", {}, False),
+                                             ("harness_scene12.npz", dict(num_steps_taken=2, Nobs=4), True)])
+def test_driver_replays_reference_parameter_sequence(name, over, sinus):
+    """Feed the recorded solutions to this repo's driver: every parameter vector it sends and the
+    trajectory it integrates must equal what the reference's own loop produced, bit for bit."""
+    d = load(name)
+    cfg = load_config(**over)
+    dyn = []
+    if "dyn_obs" in d.files:
+        dyn = [[[o[0], o[1]], [o[2], o[3]], o[4], o[5], o[6], o[7]] for o in d["dyn_obs"]]
+    route = harness.Route(cfg, tuple(d["start"]), tuple(d["end"]), [tuple(p) for p in d["path"]],
+                          [tuple(v) for v in d["vertices"]], dyn, sinus)
+    rec = []
+    mng = ReplayManager(d["solutions"], d["exit"])
+    gen = TrajectoryGenerator(cfg, sinus_object=sinus, manager_factory=lambda: mng)
+    try:
+        out = gen.run(route, record_parameters=rec)
+    except KeyboardInterrupt:
+        out = None
+    P = np.array(rec[:len(d["params"])])
+    assert P.shape == d["params"].shape
+    assert np.array_equal(P, d["params"])
+    if out is not None:                                   # scene 1 runs to the goal
+        xx, xy, uv, uw = out[:4]
+        assert np.array_equal(xx, d["xx"]) and np.array_equal(xy, d["xy"])
+        assert np.array_equal(uv, d["uv"]) and np.array_equal(uw, d["uw"])
+        assert abs(xx[-1] - d["end"][0]) <= 0.05 and abs(xy[-1] - d["end"][1]) <= 0.05
+
+
+def test_batched_receding_horizon_matches_sequential():
+    """B robots in lock step == B sequential runs (same assembly, same warm starts), oracle as solver."""
+    from conftest import oracle_for
+    cfg = named_config("cfg4")
+    o = oracle_for(cfg)
+    route = harness.scene_route(cfg, 1)
+    starts = [route.start, (1.2, 5.3, 0.6), (0.8, 4.6, 0.9)]
+    brh = BatchedRecedingHorizon(route, starts)
+    solve = lambda P, U, Y: o.solve_batch(P, u0=U, y0=Y, threads=3)          # noqa: E731
+    Ps = [brh.step(solve)[0] for _ in range(4)]
+    for b, s in enumerate(starts):
+        one = BatchedRecedingHorizon(route, [s])
+        for k in range(4):
+            P1, _ = one.step(solve)
+            assert np.array_equal(P1[0], Ps[k][b])
+        assert one.states[0] == brh.states[b]
+
+
+def test_synthetic_batch_is_deterministic_and_well_formed():
+    cfg = named_config("cfg1")
+    A, B = harness.synthetic_batch(cfg, 11, 64, 5), harness.synthetic_batch(cfg, 11, 64, 5)
+    assert np.array_equal(A, B) and A.shape == (64, 430)
+    assert np.array_equal(A[:, 10:20], np.tile(cfg.weights(), (64, 1)))
+    assert np.all(A[:, 20:40] <= cfg.lin_vel_max) and np.all(A[:, 20:40] >= 0)
+    r = A[:, 40:70].reshape(64, 10, 3)[:, :, 2]
+    assert set(np.unique(r)) <= {0.0, 0.5}
+    dyn = A[:, 70:370].reshape(64, 3, 20, 5)
+    assert np.all(dyn[..., 2:4] == 1.0) and np.all(dyn[..., [0, 1, 4]] == 0.0)     # reference padding
+    C = harness.synthetic_batch(named_config("cfg3"), 11, 8, 1, synthetic_circles=True)
+    assert C.shape == (8, 550) and np.all(C[:, 40:190].reshape(8, 50, 3)[:, :, 2] == 0.5)
