@@ -31,6 +31,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F64_VALU_TFLOPS = 78.6      # MI355X vector f64 (= f64 MFMA dense peak); MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per launch of the cfg1 workload from rocprofv3 PMC passes (profiles/r01/pmc_fetch.csv,
+# pmc_write.csv: FETCH_SIZE x 1 KiB x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md] + WRITE_SIZE x 1 KiB)
+PMC_TRAFFIC_BYTES = {"cfg1": 2 * 17391.9375 * 1024 + 11335.875 * 1024}
 
 
 def flop_model(cfg):
@@ -156,7 +159,8 @@ def main():
                              "MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},
         "roofline_hbm": {"bound": "hbm", "achieved": bytes_alg / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": None, "bytes_per_launch": bytes_alg},
+                         "traffic": PMC_TRAFFIC_BYTES.get(args.config) if B == 8192 else None, "bytes_per_launch": bytes_alg,
+                         "traffic_source": "profiles/r01/pmc_fetch.csv + pmc_write.csv (separate --pmc passes)"},
     }
 
     if not args.no_cpu_baseline:
