@@ -40,6 +40,8 @@ struct LdsMap {
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
+    int dyn;     // NDYN_MAX x 6 x P per-stage ellipse data
+    int vec;     // 4 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+
     int rho;     // m
     int S, Y;    // m slots x N lanes x (v, w)
     int total;
@@ -80,9 +82,13 @@ typedef __attribute__((address_space(3))) dbl2 lds_double2;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     \
     } while (0)
 
-// per-stage data of the dynamic ellipses, held in registers by the stage's lane
+// per-stage data of the dynamic ellipses: six values per (ellipse, stage), kept in the LDS slice as
+// [ellipse][field][stage] so the stage's lane reads its column conflict-free
+enum { DY_EX = 0, DY_EY, DY_CA, DY_SA, DY_IRX2, DY_IRY2, DY_FIELDS };
 struct DynStage {
-    double ex[NDYN_MAX], ey[NDYN_MAX], ca[NDYN_MAX], sa[NDYN_MAX], irx2[NDYN_MAX], iry2[NDYN_MAX];
+    const lds_double *col;     // this lane's column
+    int stride;                // lanes per group (P)
+    __device__ __forceinline__ double get(int k, int f) const { return col[(k * DY_FIELDS + f) * stride]; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -105,17 +111,27 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
         L[a.map.obs + 3 * k + 2] = r * r;
     }
     const double *pd = ps + 3 * nobs;
+    {
+        lds_double *col = L + a.map.dyn + t;
+        dyn.col = col;
+        dyn.stride = P;
 #pragma unroll
-    for (int k = 0; k < NDYN_MAX; ++k) {
-        dyn.ex[k] = dyn.ey[k] = dyn.ca[k] = dyn.sa[k] = 0.0;
-        dyn.irx2[k] = dyn.iry2[k] = 1.0;
-        if (k < ndyn && t < N) {
-            const double *e = pd + (k * N + t) * 5;
-            dyn.ex[k] = e[0];
-            dyn.ey[k] = e[1];
-            dyn.irx2[k] = 1.0 / (e[2] * e[2]);
-            dyn.iry2[k] = 1.0 / (e[3] * e[3]);
-            sincos_cw(e[4], dyn.sa[k], dyn.ca[k]);
+        for (int k = 0; k < NDYN_MAX; ++k) {
+            double ex = 0.0, ey = 0.0, ca = 0.0, sa = 0.0, irx2 = 1.0, iry2 = 1.0;
+            if (k < ndyn && t < N) {
+                const double *e = pd + (k * N + t) * 5;
+                ex = e[0];
+                ey = e[1];
+                irx2 = 1.0 / (e[2] * e[2]);
+                iry2 = 1.0 / (e[3] * e[3]);
+                sincos_cw(e[4], sa, ca);
+            }
+            col[(k * DY_FIELDS + DY_EX) * P] = ex;
+            col[(k * DY_FIELDS + DY_EY) * P] = ey;
+            col[(k * DY_FIELDS + DY_CA) * P] = ca;
+            col[(k * DY_FIELDS + DY_SA) * P] = sa;
+            col[(k * DY_FIELDS + DY_IRX2) * P] = irx2;
+            col[(k * DY_FIELDS + DY_IRY2) * P] = iry2;
         }
     }
     const double *pr = pd + 5 * ndyn * N;
@@ -179,15 +195,22 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         const lds_double *sg = L + a.map.seg;
         const int nseg4 = (N - 1 + 3) & ~3;
         for (int i = 0; i < nseg4; i += 4, sg += 4 * SEG_STRIDE) {
+            // all twenty LDS reads of the trip are issued before any arithmetic (the scheduling barrier
+            // keeps the compiler from sinking them next to their uses), then four independent chains run
+            double sd[4][5];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int f = 0; f < 5; ++f) sd[j][f] = sg[j * SEG_STRIDE + f];
+            __builtin_amdgcn_sched_barrier(0);
             double d2[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                   // four independent chains per trip
-                const lds_double *q = sg + j * SEG_STRIDE;
-                const double px = xn - q[0], py = yn - q[1];
-                const double dot = fma(px, q[2], py * q[3]);
-                const double that = dot * q[4];
+            for (int j = 0; j < 4; ++j) {
+                const double px = xn - sd[j][0], py = yn - sd[j][1];
+                const double dot = fma(px, sd[j][2], py * sd[j][3]);
+                const double that = dot * sd[j][4];
                 const double tst = fmin(fmax(that, 0.0), 1.0);
-                const double ex = fma(tst, q[2], -px), ey = fma(tst, q[3], -py);
+                const double ex = fma(tst, sd[j][2], -px), ey = fma(tst, sd[j][3], -py);
                 d2[j] = fma(ex, ex, ey * ey);
             }
 #pragma unroll
@@ -226,9 +249,13 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         const lds_double *ob = L + a.map.obs;
         const int nobs2 = (nobs + 1) & ~1;
         for (int k = 0; k < nobs2; k += 2, ob += 6) {       // activity scan, two circles per trip, no branches
-            const double dx0 = xn - ob[0], dy0 = yn - ob[1], dx1 = xn - ob[3], dy1 = yn - ob[4];
-            const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ob[2]));              // (:112)
-            const double h1 = fma(-dy1, dy1, fma(-dx1, dx1, ob[5]));
+            double od[6];
+#pragma unroll
+            for (int f = 0; f < 6; ++f) od[f] = ob[f];
+            __builtin_amdgcn_sched_barrier(0);
+            const double dx0 = xn - od[0], dy0 = yn - od[1], dx1 = xn - od[3], dy1 = yn - od[4];
+            const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, od[2]));              // (:112)
+            const double h1 = fma(-dy1, dy1, fma(-dx1, dx1, od[5]));
             const unsigned long long b0 = __ballot(in && h0 > 0.0), b1 = __ballot(in && h1 > 0.0);
             act |= (unsigned long long)(b0 != 0) << k;
             act |= (unsigned long long)(b1 != 0) << (k + 1);
@@ -246,10 +273,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
             if (k < ndyn) {
-                const double dx = xn - dyn.ex[k], dy = yn - dyn.ey[k];
-                const double ea = fma(dx, dyn.ca[k], dy * dyn.sa[k]);
-                const double eb = fma(dx, dyn.sa[k], -(dy * dyn.ca[k]));
-                const double h = fma(-(eb * eb), dyn.iry2[k], fma(-(ea * ea), dyn.irx2[k], 1.0));   // (:118)
+                const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
+                const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
+                const double ea = fma(dx, ca, dy * sa);
+                const double eb = fma(dx, sa, -(dy * ca));
+                const double h = fma(-(eb * eb), dyn.get(k, DY_IRY2), fma(-(ea * ea), dyn.get(k, DY_IRX2), 1.0));   // (:118)
                 const double hm = in ? fmax(h, 0.0) : 0.0;
                 if (__any(hm > 0.0)) {
                     act_dyn |= 1u << k;
@@ -295,14 +323,16 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         for (int k = 0; k < NDYN_MAX; ++k) {
             if (act_dyn & (1u << k)) {
                 const double wk = -2.0 * (c * f2[nobs + k]);
-                const double dx = xn - dyn.ex[k], dy = yn - dyn.ey[k];
-                const double ea = fma(dx, dyn.ca[k], dy * dyn.sa[k]);
-                const double eb = fma(dx, dyn.sa[k], -(dy * dyn.ca[k]));
-                const double h = fma(-(eb * eb), dyn.iry2[k], fma(-(ea * ea), dyn.irx2[k], 1.0));
+                const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
+                const double irx2 = dyn.get(k, DY_IRX2), iry2 = dyn.get(k, DY_IRY2);
+                const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
+                const double ea = fma(dx, ca, dy * sa);
+                const double eb = fma(dx, sa, -(dy * ca));
+                const double h = fma(-(eb * eb), iry2, fma(-(ea * ea), irx2, 1.0));
                 if (h > 0.0) {
-                    const double A = ea * dyn.irx2[k], Bq = eb * dyn.iry2[k];
-                    const double hx = fma(A, dyn.ca[k], Bq * dyn.sa[k]);
-                    const double hy = fma(A, dyn.sa[k], -(Bq * dyn.ca[k]));
+                    const double A = ea * irx2, Bq = eb * iry2;
+                    const double hx = fma(A, ca, Bq * sa);
+                    const double hy = fma(A, sa, -(Bq * ca));
                     gx = fma(wk, hx, gx);
                     gy = fma(wk, hy, gy);
                 }
@@ -399,8 +429,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     bool done = false;                       // queue exhausted for this group
     double vref = 0.0;
     DynStage dyn;
-#pragma unroll
-    for (int k = 0; k < NDYN_MAX; ++k) { dyn.ex[k] = dyn.ey[k] = dyn.ca[k] = dyn.sa[k] = 0.0; dyn.irx2[k] = dyn.iry2[k] = 1.0; }
+    dyn.col = L + a.map.dyn + t;
+    dyn.stride = P;
     // horizon vectors: (v, w) pair per lane
     double uv = 0, uw = 0, gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0;   // u, grad, grad-step, half-step, gamma*fpr
     double dv = 0, dw = 0, pv = 0, pw = 0, qv = 0, qw = 0;                                      // direction, u_plus, previous gradient
@@ -764,6 +794,9 @@ static LdsMap make_map(const nmpc_problem &pb, int m)
     mp.obs = o; o += 3 * (pb.nobs + 2);
     mp.f2 = o;  o += 2 * (pb.nobs + pb.ndyn + 1);     // one F2 array per half (dual kernel)
     mp.rho = o; o += m;
+    mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * (pb.N <= 32 ? 32 : 64);
+    o = (o + 1) & ~1;
+    mp.vec = o; o += 4 * 2 * (pb.N <= 32 ? 32 : 64);
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
     mp.S = o;   o += 2 * pb.N * m;
     mp.Y = o;   o += 2 * pb.N * m;
@@ -798,8 +831,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     hipGetDeviceProperties(&prop, device_id);
     const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * 2;       // eval kernel: two slices per wave
     if (lds_bytes > 160 * 1024) { hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
-    int per_cu = (int)((160 * 1024) / lds_bytes);
-    if (per_cu > 8) per_cu = 8;             // register budget: <= 2 waves per SIMD
+    // the solve kernels use one LDS slice per wave; resident waves per CU are bounded by LDS and by
+    // the register budget (2 waves per SIMD)
+    int per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
+    if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     h->grid_cap = prop.multiProcessorCount * per_cu;
     *out = h;

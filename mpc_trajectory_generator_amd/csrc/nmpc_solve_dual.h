@@ -48,12 +48,14 @@ __device__ __forceinline__ double fbe_value(double cost, double gamma, double sv
 }
 
 // gradient step x - gamma g and its projection on U (lanes beyond the horizon stay zero)
-#define NMPC_HALF_STEP(xv, xw)                                   \
-    do {                                                         \
-        sv_ = fma(-gamma, gv, (xv)); sw_ = fma(-gamma, gw, (xw)); \
-        hv = in ? clampd(sv_, vmin, vmax) : sv_;                 \
-        hw = in ? clampd(sw_, -wmax, wmax) : sw_;                \
+#define NMPC_HALF_STEP(xv, xw)                                                 \
+    do {                                                                       \
+        const double s1_ = fma(-gamma, gv, (xv)), s2_ = fma(-gamma, gw, (xw)); \
+        hv = in ? clampd(s1_, vmin, vmax) : s1_;                               \
+        hw = in ? clampd(s2_, -wmax, wmax) : s2_;                              \
     } while (0)
+// FBE at the cached point; the gradient step x - gamma g is recomputed (bitwise the same value)
+#define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
 
 __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
 {
@@ -67,6 +69,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
     lds_double2 *LS = (lds_double2 *)(L + a.map.S);
     lds_double2 *LY = (lds_double2 *)(L + a.map.Y);
     lds_double *Lrho = L + a.map.rho;
+    lds_double2 *Los = (lds_double2 *)(L + a.map.vec) + t;      // parked pairs, one column per stage
+    lds_double2 *Log = Los + P, *Lq = Los + 2 * P, *Lyp = Los + 3 * P;
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
 
@@ -87,10 +91,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         double uv = in ? u0[2 * t] : 0.0, uw = in ? u0[2 * t + 1] : 0.0;
         double yv = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + t] : 0.0;
         double yw = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + N + t] : 0.0;
-        double ypv = yv, ypw = yw;
-        double gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
-        double qv = 0, qw = 0;                    // gradient_u_previous (AKKT residual)
-        double osv = 0, osw = 0, ogv = 0, ogw = 0;
+        *Lyp = dbl2{yv, yw};
+        *Lq = dbl2{0.0, 0.0};                    // gradient_u_previous (AKKT residual) starts at zero
+        double gv = 0, gw = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
         double pv = 0, pw = 0;                    // line-search trial point of THIS half
         double zv = 0, zw = 0;                    // query point of THIS half
         bool need_grad = true;
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 norm_r = sqrt(nr2);
                 bool exit_now = false;
                 if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test
-                    const double a1 = rv / gamma + (gv - qv), a2 = rw / gamma + (gw - qw);
+                    const dbl2 q_ = *Lq;
+                    const double a1 = rv / gamma + (gv - q_.x), a2 = rw / gamma + (gw - q_.y);
                     exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu);
                 }
                 if (exit_now) {
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     if (lb_first) {
                         n_first = false; n_take_old = true;
                     } else {
-                        const double s1 = uv - osv, s2 = uw - osw, y1 = rv - ogv, y2 = rw - ogw;
+                        const dbl2 os_ = *Los, og_ = *Log;
+                        const double s1 = uv - os_.x, s2 = uw - os_.y, y1 = rv - og_.x, y2 = rw - og_.y;
                         const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
                         if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                             }
                         }
                     }
-                    rhs_ls = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane) - sigma * nr2;
+                    rhs_ls = NMPC_FBE(uv, uw) - sigma * nr2;
                     tau = 1.0; ls_n = 0;
                     const double omt = 1.0 - tau;
                     pv = fma(-tau, dv, fma(-omt, rv, uv));
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     f_back = true;                                       // (speculation discarded)
                 } else {
                     if (state == D_LIP) {
-                        lb_first = false; osv = uv; osw = uw; ogv = rv; ogw = rw;     // first pair after a reset: only remembered
+                        lb_first = false; *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw};      // first pair after a reset: only remembered
                         if (iteration == 0) {
                             // first iteration: plain forward-backward step; psi, grad psi at u_bar are at hand
                             n_grad++;
@@ -316,18 +321,18 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                             f_end = true;
                         } else {
                             dv = rv; dw = rw;                            // empty buffer: d = r
-                            rhs_ls = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane) - sigma * nr2;
+                            rhs_ls = NMPC_FBE(uv, uw) - sigma * nr2;
                             tau = 1.0; ls_n = 0;
                             f_trials = true;
                         }
                     } else {
                         lb_first = n_first; lb_head = n_head; lb_active = n_active; H0 = n_H0;      // commit
-                        if (n_take_old) { osv = uv; osw = uw; ogv = rv; ogw = rw; }
+                        if (n_take_old) { *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw}; }
                         n_grad++;
-                        qv = gv; qw = gw;                                // cache_previous_gradient
+                        *Lq = dbl2{gv, gw};                              // cache_previous_gradient
                         cost = psiB; gv = gBv; gw = gBw;
                         NMPC_HALF_STEP(pv, pw);
-                        const double lhs = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane);
+                        const double lhs = NMPC_FBE(pv, pw);
                         if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; }
                         else { uv = pv; uw = pw; f_end = true; }
                     }
@@ -338,28 +343,29 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 both_halves(pv, pAv, pBv);
                 both_halves(pw, pAw, pBw);
                 n_grad++;
-                qv = gv; qw = gw;
+                *Lq = dbl2{gv, gw};
                 cost = psiA; gv = gAv; gw = gAw;
                 pv = pAv; pw = pAw;
                 NMPC_HALF_STEP(pv, pw);
-                double lhs = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane);
+                double lhs = NMPC_FBE(pv, pw);
                 bool accept = true;
                 if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) {
                     tau /= 2.0; ls_n++;
                     n_grad++;
-                    qv = gv; qw = gw;
+                    *Lq = dbl2{gv, gw};
                     cost = psiB; gv = gBv; gw = gBw;
                     pv = pBv; pw = pBw;
                     NMPC_HALF_STEP(pv, pw);
-                    lhs = fbe_value<P>(cost, gamma, sv_, sw_, hv, hw, gv, gw, lane);
+                    lhs = NMPC_FBE(pv, pw);
                     if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; accept = false; }
                 }
                 if (accept) { uv = pv; uw = pw; f_end = true; }
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
-                ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
-                ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+                const double ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
+                const double ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+                *Lyp = dbl2{ypv, ypw};
                 const double d1 = ypv - yv, d2 = ypw - yw;
                 dy_norm_plus = sqrt(group_sum<P>(in ? fma(d1, d1, d2 * d2) : 0.0, lane));
                 f2_norm_plus = sqrt(pen);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         if (in && h == 0) {
             double *uo = a.u + (size_t)inst * a.n_u;
             uo[2 * t] = uv; uo[2 * t + 1] = uw;
-            if (a.y_out) { a.y_out[(size_t)inst * a.n1 + t] = ypv; a.y_out[(size_t)inst * a.n1 + N + t] = ypw; }
+            if (a.y_out) { const dbl2 yp_ = *Lyp; a.y_out[(size_t)inst * a.n1 + t] = yp_.x; a.y_out[(size_t)inst * a.n1 + N + t] = yp_.y; }
         }
         if (lane == 0 && a.st) {
             nmpc_status s;
@@ -416,5 +422,6 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
     }
 }
 #undef NMPC_HALF_STEP
+#undef NMPC_FBE
 
 }  // namespace nmpc
