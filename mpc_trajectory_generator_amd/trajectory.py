@@ -194,3 +194,150 @@ class BatchedRecedingHorizon:
         self.U, self.Y = U, Y
         self.advance(U)
         return P, st
+
+
+class VectorizedRecedingHorizon:
+    """``BatchedRecedingHorizon`` with the per-robot Python loops replaced by NumPy array operations
+    (BASELINE config 4: 8192 robots x 100 steps).  Same quantities, same order of operations per
+    robot -- the test suite demands bit-identical parameter vectors against the loop version.
+
+    All robots share the route; dynamic obstacles are per robot: ``dyn_obs`` is ``None`` or a tuple of
+    arrays ``(p1 [B, K, 2], p2 [B, K, 2], freq [B, K], rx [B, K], ry [B, K], angle [B, K])``.
+    """
+
+    def __init__(self, route: harness.Route, starts, dyn_obs=None):
+        cfg = self.cfg = route.cfg
+        self.route = route
+        self.B = B = len(starts)
+        self.state = np.array(starts, dtype=np.float64).reshape(B, 3)
+        self.traj = [self.state.copy()]
+        self.last_u = np.zeros((B, cfg.nu))
+        self.has_input = False
+        self.idx = np.zeros(B, dtype=np.int64)
+        self.t = 0
+        self.dyn_obs = dyn_obs
+        K = 0 if dyn_obs is None else dyn_obs[0].shape[1]
+        assert K <= cfg.Ndynobs
+        self.K = K
+        d = np.zeros((B, cfg.Ndynobs, cfg.N_hor, cfg.ndynobs))
+        d[..., 2] = 1.0
+        d[..., 3] = 1.0                                           # padding: unit radii (path_generator.py:274-280)
+        self.dyn = d
+        self.U = np.zeros((B, cfg.n_u))
+        self.Y = np.zeros((B, cfg.n1))
+        self.x_ref = np.array(route.x_ref)
+        self.y_ref = np.array(route.y_ref)
+        self.th_ref = np.array(route.theta_ref)
+        self.n = len(self.x_ref)
+        self.vert = np.array(route.vertices, dtype=np.float64).reshape(-1, 2)
+        self.done = np.zeros(B, dtype=bool)
+
+    # dynamic-obstacle prediction for all robots: visibility.py:156-166,199-216 (linear law)
+    def _predict(self, t0, horizon):
+        cfg = self.cfg
+        p1, p2, freq, rx, ry, ang = self.dyn_obs
+        times = np.linspace(t0, t0 + horizon * cfg.ts, horizon)                       # (:204)
+        s = np.abs(np.sin(freq[:, :, None] * times[None, None, :]))                  # [B, K, H]
+        pos = s[..., None] * p1[:, :, None, :] + (1 - s[..., None]) * p2[:, :, None, :]
+        pad = cfg.vehicle_width / 2 + cfg.vehicle_margin
+        out = np.empty(pos.shape[:3] + (5,))
+        out[..., 0:2] = pos
+        out[..., 2] = (rx + pad)[:, :, None]
+        out[..., 3] = (ry + pad)[:, :, None]
+        out[..., 4] = ang[:, :, None]
+        return out
+
+    def assemble(self):
+        cfg, route, B, N, n = self.cfg, self.route, self.B, self.cfg.N_hor, self.n
+        s = cfg.num_steps_taken
+        x, y = self.state[:, 0], self.state[:, 1]
+        # static circles (path_generator.py:295-304 + visibility.py:141-148 with look-back 0)
+        cons = np.zeros((B, cfg.Nobs, cfg.nobs))
+        nv = len(self.vert)
+        if nv:
+            if cfg.Nobs >= nv:
+                cons[:, :nv, 0:2] = self.vert[None]
+                cons[:, :nv, 2] = route.radius
+            else:
+                dist = np.linalg.norm(self.vert[None, :, :] - self.state[:, None, 0:2], axis=2)
+                lb = np.argmin(dist, axis=1)
+                ub = min(nv, cfg.Nobs)
+                j = lb[:, None] + np.arange(cfg.Nobs)[None, :]
+                ok = j < ub
+                jj = np.minimum(j, nv - 1)
+                cons[..., 0:2] = np.where(ok[..., None], self.vert[jj], 0.0)
+                cons[..., 2] = np.where(ok, route.radius, 0.0)
+        # dynamic ellipses (path_generator.py:306-316)
+        if self.K:
+            if self.t == 0:
+                self.dyn[:, :self.K] = self._predict(0.0, N)
+            else:
+                self.dyn[:, :, :N - s] = self.dyn[:, :, s:].copy()
+                self.dyn[:, :self.K, N - s:] = self._predict((self.t + N - s) * cfg.ts, s)
+        # closest reference sample in the sliding window (:320-325)
+        lb = np.maximum(0, self.idx - s)
+        ub = np.minimum(n, self.idx + 5 * s)
+        w = np.arange(6 * s)
+        j = lb[:, None] + w[None, :]
+        ok = j < ub[:, None]
+        jj = np.minimum(j, n - 1)
+        d = np.linalg.norm(np.stack([self.x_ref[jj] - x[:, None], self.y_ref[jj] - y[:, None]], axis=2), axis=2)
+        d = np.where(ok, d, np.inf)
+        self.idx = lb + np.argmin(d, axis=1)
+        idx = self.idx
+        # horizon references and target (:326-341)
+        end = np.array(route.end, dtype=np.float64)
+        j = idx[:, None] + np.arange(N)[None, :]
+        ok = j < n
+        jj = np.minimum(j, n - 1)
+        refs = np.empty((B, N, 3))
+        refs[..., 0] = np.where(ok, self.x_ref[jj], end[0])
+        refs[..., 1] = np.where(ok, self.y_ref[jj], end[1])
+        refs[..., 2] = np.where(ok, self.th_ref[jj], end[2])
+        far = idx + N < n
+        jf = np.minimum(idx + N, n - 1)
+        xf = np.where(far[:, None], np.stack([self.x_ref[jf], self.y_ref[jf], self.th_ref[jf]], axis=1), end[None, :])
+        # velocity reference with the braking profile (:343-361)
+        bv, bd, base = np.array(route.brake_velocities), np.array(route.brake_distances), route.base_speed
+        vel = np.full((B, N), base)
+        brake = (idx + N) >= n - bd[0] / base
+        num_base = np.minimum(n - idx - 1, N)
+        k = np.arange(N)[None, :]
+        nb = num_base[:, None]
+        tail = np.where(k - nb < len(bv), bv[np.clip(k - nb, 0, len(bv) - 1)], 0.0)
+        vel_b = np.where(k < nb, base, tail)
+        vel = np.where(brake[:, None], vel_b, vel)
+        for b in np.where(brake & (num_base == 0))[0]:                      # inside the last sample: distance-based (:347-351)
+            dist_to_goal = math.sqrt((self.state[b, 0] - end[0]) ** 2 + (self.state[b, 1] - end[1]) ** 2)
+            vr = [v for (v, dd) in zip(bv, bd) if dd <= dist_to_goal][:N]
+            vel[b] = np.array(vr + [0.0] * (N - len(vr)))
+        W = np.tile(np.array(cfg.weights()), (B, 1))
+        P = np.concatenate([self.state, self.last_u, xf, self.last_u, W, vel, cons.reshape(B, -1),
+                            self.dyn.reshape(B, -1), refs.reshape(B, -1)], axis=1)
+        assert P.shape[1] == cfg.n_p
+        return P
+
+    def advance(self, U):
+        cfg = self.cfg
+        s = cfg.num_steps_taken
+        st = self.state.copy()
+        for i in range(s):                                                  # mpc_generator.py:225-235
+            v, w = U[:, i * cfg.nu], U[:, 1 + i * cfg.nu]
+            th = st[:, 2]
+            # per robot: x + ts*(v*cos(theta)) with math.cos -> np.cos is the same libm call
+            st = np.stack([st[:, 0] + cfg.ts * (v * np.cos(th)), st[:, 1] + cfg.ts * (v * np.sin(th)),
+                           th + cfg.ts * w], axis=1)
+            self.traj.append(st.copy())
+        self.state = st
+        self.last_u = U[:, (s - 1) * cfg.nu:s * cfg.nu].copy()
+        self.has_input = True
+        end = self.route.end
+        self.done = (np.abs(st[:, 0] - end[0]) <= 0.05) & (np.abs(st[:, 1] - end[1]) <= 0.05) & (np.abs(self.last_u[:, 0]) < 0.005)
+        self.t += s
+
+    def step(self, solve_fn):
+        P = self.assemble()
+        U, Y, st = solve_fn(P, self.U, self.Y)
+        self.U, self.Y = U, Y
+        self.advance(U)
+        return P, st
