@@ -56,6 +56,18 @@ __device__ __forceinline__ void row_pair_split(double v, double &even_rows, doub
     odd_rows = __hiloint2double(hi[1], lo[1]);
 }
 
+// bitwise OR over all 64 lanes, returned as a wave-uniform scalar
+__device__ __forceinline__ unsigned wave_or(unsigned v)
+{
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+    // one lane per row now holds the row's OR in every lane of the row: combine the four rows
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+
 // sum over the P lanes of the group, result in every lane.  Butterfly over lane^1, ^2, ^4, ^8, ^16
 // (^32); a + b == b + a bitwise, so every lane ends with the value of the adjacent-pair tree.
 template <int P>

@@ -103,7 +103,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     if (t >= 8 && t < 18) L[a.map.sc + t] = p[t + 2];       // ten weights p[10:20]
     vref = t < N ? p[NZ + t] : 0.0;
     const double *ps = p + NZ + N;
-    for (int k = t; k < ((nobs + 1) & ~1); k += P) {       // padded to an even count with an inert zero circle
+    for (int k = t; k < ((nobs + 3) & ~3); k += P) {       // padded to a multiple of 4 with inert zero circles
         const bool real = k < nobs;
         const double r = real ? ps[3 * k + 2] : 0.0;
         L[a.map.obs + 3 * k] = real ? ps[3 * k] : 0.0;
@@ -154,6 +154,12 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
 // ---------------------------------------------------------------------------------------------
 // psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); F2_k left in the LDS slice
 // ---------------------------------------------------------------------------------------------
+#ifdef NMPC_PROFILE
+#define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_evt[i] += t_ - nmpc_evl; nmpc_evl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ long long nmpc_dummy_;
+#else
+#define NMPC_EVTICK(i) do { } while (0)
+#endif
 template <int P>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
@@ -163,6 +169,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
     const bool in = t < N;
+#ifdef NMPC_PROFILE
+    extern __shared__ long long nmpc_prof_lds[];
+    long long *nmpc_evt = nmpc_prof_lds + 4096 + (threadIdx.x == 0 ? 0 : 8);   // lane 0 accumulates; others to a dummy row
+    long long nmpc_evl = __builtin_amdgcn_s_memtime();
+#endif
     const lds_double *sc = L + a.map.sc;
     const double x0 = sc[SC_X0], y0 = sc[SC_Y0], th0 = sc[SC_TH0];
     const double xf = sc[SC_XF], yf = sc[SC_YF], thf = sc[SC_THF];
@@ -178,6 +189,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const double yp = from_prev<P>(yn, lane, y0);
 
     const double half_c = 0.5 * c;
+    NMPC_EVTICK(0);     // rollout
 
     double acc = (sc[SC_RV] * zv) * zv;                                           // (:84)
     acc = fma(sc[SC_RW] * zw, zw, acc);
@@ -214,10 +226,13 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                 d2[j] = fma(ex, ex, ey * ey);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (d2[j] < best) { best = d2[j]; bi = i + j; }
+            for (int j = 0; j < 4; ++j) {                   // strict <: the first minimum keeps its index
+                bi = d2[j] < best ? i + j : bi;
+                best = fmin(best, d2[j]);
+            }
         }
     }
+    NMPC_EVTICK(1);     // stage cost + CTE loop
     acc = fma(sc[SC_QCTE], best, acc);                                            // (:144)
     // accelerations (:160-161), their cost (:170-171) and the ALM term
     const double vprev = from_prev<P>(zv, lane, sc[SC_VINIT]);
@@ -238,50 +253,68 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     av_out = av;
     aw_out = aw;
     const double fsum = group_sum<P>(acc, lane);
+    NMPC_EVTICK(2);     // accelerations, ALM term, cost sum
 
     // obstacle penalties on the post-update state (:106-119).  F2_k = sum_t max(0, h_kt); an obstacle
     // that no stage of either instance in this wave touches contributes exactly 0 and is skipped
     // (wave-uniform branch); its bit in `act` stays clear so the adjoint sweep skips it too.
     double pen = 0.0;
-    unsigned long long act = 0ull;
-    unsigned act_dyn = 0u;
+    unsigned long long act = 0ull;      // wave-uniform: circles some stage is inside of
+    unsigned act_dyn = 0u;              // wave-uniform: ellipses some stage is inside of
+    unsigned m_lo = 0u, m_hi = 0u, m_dy = 0u;       // per lane: which circles / ellipses THIS stage is inside of
     {
         const lds_double *ob = L + a.map.obs;
-        const int nobs2 = (nobs + 1) & ~1;
-        for (int k = 0; k < nobs2; k += 2, ob += 6) {       // activity scan, two circles per trip, no branches
-            double od[6];
+        const int nobs4 = (nobs + 3) & ~3;
+        for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, VALU only
+            double od[12];
 #pragma unroll
-            for (int f = 0; f < 6; ++f) od[f] = ob[f];
+            for (int f = 0; f < 12; ++f) od[f] = ob[f];
             __builtin_amdgcn_sched_barrier(0);
-            const double dx0 = xn - od[0], dy0 = yn - od[1], dx1 = xn - od[3], dy1 = yn - od[4];
-            const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, od[2]));              // (:112)
-            const double h1 = fma(-dy1, dy1, fma(-dx1, dx1, od[5]));
-            const unsigned long long b0 = __ballot(in && h0 > 0.0), b1 = __ballot(in && h1 > 0.0);
-            act |= (unsigned long long)(b0 != 0) << k;
-            act |= (unsigned long long)(b1 != 0) << (k + 1);
+            unsigned bits = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
+                const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
+                bits |= (in && h > 0.0 ? 1u : 0u) << j;
+            }
+            if (k < 32) m_lo |= bits << k; else m_hi |= bits << (k - 32);
         }
-        for (unsigned long long rem = act; rem;) {
-            const int k = __builtin_ctzll(rem);
-            rem &= rem - 1;
-            const lds_double *o1 = L + a.map.obs + 3 * k;
-            const double dx = xn - o1[0], dy = yn - o1[1];
-            const double h = fma(-dy, dy, fma(-dx, dx, o1[2]));
-            const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
-            if (t == 0) L[f2off + k] = f2;
-            pen = fma(f2, f2, pen);
-        }
+        NMPC_EVTICK(5);     // static circle scan
+        double dyh[NDYN_MAX];
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
+            dyh[k] = 0.0;
             if (k < ndyn) {
                 const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
                 const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
                 const double ea = fma(dx, ca, dy * sa);
                 const double eb = fma(dx, sa, -(dy * ca));
                 const double h = fma(-(eb * eb), dyn.get(k, DY_IRY2), fma(-(ea * ea), dyn.get(k, DY_IRX2), 1.0));   // (:118)
-                const double hm = in ? fmax(h, 0.0) : 0.0;
-                if (__any(hm > 0.0)) {
-                    act_dyn |= 1u << k;
-                    const double f2 = group_sum<P>(hm, lane);
+                dyh[k] = in ? fmax(h, 0.0) : 0.0;
+                m_dy |= (dyh[k] > 0.0 ? 1u : 0u) << k;
+            }
+        }
+        NMPC_EVTICK(6);     // ellipse scan
+        // F2_k = sum_t max(0, h_kt).  An obstacle no stage in this wave is inside of contributes exactly 0
+        // and is skipped; typically nothing is touched and the whole block is one uniform branch.
+        if (__any((m_lo | m_hi | m_dy) != 0u)) {
+            const unsigned u_lo = wave_or(m_lo), u_hi = nobs > 32 ? wave_or(m_hi) : 0u;
+            act = ((unsigned long long)u_hi << 32) | u_lo;
+            act_dyn = ndyn > 0 ? wave_or(m_dy) : 0u;
+            for (unsigned long long rem = act; rem;) {
+                const int k = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                const lds_double *o1 = L + a.map.obs + 3 * k;
+                const double dx = xn - o1[0], dy = yn - o1[1];
+                const double h = fma(-dy, dy, fma(-dx, dx, o1[2]));
+                const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
+                if (t == 0) L[f2off + k] = f2;
+                pen = fma(f2, f2, pen);
+            }
+#pragma unroll
+            for (int k = 0; k < NDYN_MAX; ++k) {
+                if (act_dyn & (1u << k)) {
+                    const double f2 = group_sum<P>(dyh[k], lane);
                     if (t == 0) L[f2off + nobs + k] = f2;
                     pen = fma(f2, f2, pen);
                 }
@@ -290,6 +323,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     }
     psi = fma(half_c, pen, fsum);
     pen_out = pen;
+    NMPC_EVTICK(3);     // obstacles
     if (!want_grad) return;
     NMPC_WAVE_SYNC();          // F2_k written by lane 0 of the group are read by all its lanes below
 
@@ -363,6 +397,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     g2 = fma(ts, St, g2);
     gv = in ? g1 : 0.0;
     gw = in ? g2 : 0.0;
+    NMPC_EVTICK(4);     // adjoint sweep
 }
 
 // dot product of two horizon vectors (lane t holds the (v_t, w_t) pair)
@@ -791,7 +826,7 @@ static LdsMap make_map(const nmpc_problem &pb, int m)
     int o = 0;
     mp.sc = o;  o += 20;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 3);
-    mp.obs = o; o += 3 * (pb.nobs + 2);
+    mp.obs = o; o += 3 * (pb.nobs + 4);
     mp.f2 = o;  o += 2 * (pb.nobs + pb.ndyn + 1);     // one F2 array per half (dual kernel)
     mp.rho = o; o += m;
     mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * (pb.N <= 32 ? 32 : 64);
@@ -879,7 +914,11 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     // one instance per wave: N_hor <= 32 runs the dual-evaluation kernel (two query points per
     // pass), longer horizons the one-point-per-pass kernel with the whole wave as one group
     const int grid = B < h->grid_cap ? B : h->grid_cap;
+#ifdef NMPC_PROFILE
+    const size_t lds = 4096 * 8 + 256;
+#else
     const size_t lds = (size_t)h->map.total * sizeof(double);
+#endif
     if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());

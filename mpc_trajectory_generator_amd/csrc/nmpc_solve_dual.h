@@ -98,6 +98,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         double zv = 0, zw = 0;                    // query point of THIS half
         bool need_grad = true;
         double cost = 0, Lc = 0, gamma = 0, sigma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0, norm_h = 0, H0 = 1;
+        double fbe_u = 0;                         // FBE at the current iterate, valid while fbe_ok (an accepted
+        bool fbe_ok = false;                      // trial's FBE is the next iteration's: same operands, same bits)
         int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
         bool lb_first = true;
         // tentative L-BFGS update of the current iteration (committed when the Lipschitz test passes)
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
         bool running = true;
 #ifdef NMPC_PROFILE
+        { extern __shared__ long long nmpc_prof_lds[]; if (lane < 16) nmpc_prof_lds[4096 + lane] = 0; }
         long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
 #define NMPC_TICK(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
         NMPC_TICK(tk0);
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
             if (f_back) {
                 f_back = false;
                 lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
+                fbe_ok = false;
                 Lc *= 2.0; gamma /= 2.0;
                 sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 c_lip = GAMMA_L_COEFF / (2.0 * gamma);
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                             }
                         }
                     }
-                    rhs_ls = NMPC_FBE(uv, uw) - sigma * nr2;
+                    if (!fbe_ok) { fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
+                    rhs_ls = fbe_u - sigma * nr2;
                     tau = 1.0; ls_n = 0;
                     const double omt = 1.0 - tau;
                     pv = fma(-tau, dv, fma(-omt, rv, uv));
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
+                fbe_ok = false;
                 f_begin = true;
             } else if (state == D_LIP || state == D_ITER) {
                 // Lipschitz test on psi(u_bar) (half 0).  D_LIP: sequential (iteration 0, or after a
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                             uv = hv; uw = hw;
                             cost = psiA; gv = gAv; gw = gAw;
                             NMPC_HALF_STEP(uv, uw);
+                            fbe_ok = false;
                             f_end = true;
                         } else {
                             dv = rv; dw = rw;                            // empty buffer: d = r
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                         NMPC_HALF_STEP(pv, pw);
                         const double lhs = NMPC_FBE(pv, pw);
                         if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; }
-                        else { uv = pv; uw = pw; f_end = true; }
+                        else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
                     }
                 }
             } else if (state == D_LS) {
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     lhs = NMPC_FBE(pv, pw);
                     if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; accept = false; }
                 }
-                if (accept) { uv = pv; uw = pw; f_end = true; }
+                if (accept) { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
@@ -414,7 +421,14 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
             s.cost = last_cost;
             s.solve_time_ms = 0.0;
 #ifdef NMPC_PROFILE
-            s.last_problem_norm_fpr = (double)cyc_eval; s.delta_y_norm_over_c = (double)cyc_top; s.f2_norm = (double)cyc_post;
+            {
+                extern __shared__ long long nmpc_prof_lds[];
+                const long long *e = nmpc_prof_lds + 4096;
+                s.last_problem_norm_fpr = (double)cyc_eval; s.delta_y_norm_over_c = (double)cyc_top; s.f2_norm = (double)cyc_post;
+                s.penalty = (double)e[0]; s.cost = (double)e[1]; s.solve_time_ms = (double)e[2];
+                s.num_cost_evals = (uint32_t)(e[3] / 100); s.num_grad_evals = (uint32_t)(e[4] / 100);
+                s.num_outer_iterations = (uint32_t)(e[5] / 100); s.num_inner_iterations = (uint32_t)(e[6] / 100);
+            }
 #endif
             a.st[inst] = s;
         }
