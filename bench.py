@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--config", default="cfg1")
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--scene", type=int, default=11)
+    ap.add_argument("--routes", type=int, default=32,
+                    help="randomised start/goal pairs planned on the scene (0: the scene's own start -> end route)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,7 +79,11 @@ def main():
     cfg = named_config(args.config)
     B = args.batch
     kw = dict(synthetic_circles=(args.config in ("cfg3", "nobs50")), random_dyn=(args.config in ("cfg4", "smooth_velocity")))
-    P_host = synthetic_batch(cfg, args.scene, B, seed=rank, **kw)        # timing seeds 0..R-1
+    routes = None
+    if args.routes > 0:                                                   # "randomized start/goal" (BASELINE.json configs[1])
+        from mpc_trajectory_generator_amd.frontend import random_routes
+        routes = random_routes(cfg, args.scene, args.routes, seed=1000 + rank)
+    P_host = synthetic_batch(cfg, args.scene, B, seed=rank, routes=routes, **kw)   # timing seeds 0..R-1
     solver = BatchSolver(cfg, max_batch=B, device=local)
     d_p = torch.from_numpy(P_host).to(dev)
     d_u = torch.zeros(B, cfg.n_u, dtype=torch.float64, device=dev)
@@ -143,7 +149,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.config}: default.yaml-shaped NMPC, N_hor={cfg.N_hor}, Nobs={cfg.Nobs}, "
-                               f"Ndynobs={cfg.Ndynobs}, scene {args.scene}, batch={B}/GPU, cold start (u0=0, y0=0, c0=1), "
+                               f"Ndynobs={cfg.Ndynobs}, scene {args.scene} ({args.routes or 1} route(s): "
+                               f"{'randomised start/goal planned by the visibility-graph front-end' if args.routes else 'scene start->end'}), "
+                               f"batch={B}/GPU, cold start (u0=0, y0=0, c0=1), "
                                f"tol 1e-4, caps inner {solver.opts.max_inner}/outer {solver.opts.max_outer}",
                    "batch_per_gpu": B, "n_u": cfg.n_u, "n_p": cfg.n_p, "parallelism": f"instance-sharded x{world}"},
         "mean_inner_iters": stats[0] / stats[3], "mean_outer_iters": stats[1] / stats[3],
@@ -159,7 +167,7 @@ def main():
                              "MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},
         "roofline_hbm": {"bound": "hbm", "achieved": bytes_alg / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": PMC_TRAFFIC_BYTES.get(args.config) if B == 8192 else None, "bytes_per_launch": bytes_alg,
+                         "traffic": PMC_TRAFFIC_BYTES.get(args.config) if (B == 8192 and args.routes == 32) else None, "bytes_per_launch": bytes_alg,
                          "traffic_source": "profiles/r01/pmc_fetch.csv + pmc_write.csv (separate --pmc passes)"},
     }
 

@@ -228,9 +228,10 @@ def assemble_params(route: Route, state, last_u, idx, constraints, dyn_constrain
 # scenes: data of the reference's hard-coded maps that the benchmark configurations name
 # --------------------------------------------------------------------------------------------
 # src/visibility/graphs.py:34-43 (scene 1) and :161-170 (scene 11): obstacle polygons, start, end.
-# Waypoints are the miter-offset (vehicle_width = 0.5) corner points the reference's
-# visibility-graph A* returns for the default start/end, derived by hand (SURVEY.md section 8d,
-# config 0) -- the front-end itself needs extremitypathfinder/pyclipper, which are not available.
+# Waypoints are the miter-offset (vehicle_width = 0.5) corner points of the shortest path between the
+# default start/end: scene 1 as derived by hand in SURVEY.md section 8d (config 0), scene 11 as
+# returned by this repo's own visibility-graph planner (frontend.py; the reference's front-end needs
+# extremitypathfinder/pyclipper, which are not available).  tests/test_frontend.py re-derives both.
 SCENES = {
     1: dict(
         start=(1.0, 5.0, math.radians(45)), end=(19.0, 10.0, math.radians(0)),
@@ -239,9 +240,9 @@ SCENES = {
     ),
     11: dict(
         start=(27.8, 2.7, math.radians(90)), end=(50.3, 45.9, math.radians(0)),
-        waypoints=[(27.8, 2.7), (27.6, 5.5), (27.6, 33.5), (44.5, 33.6), (58.3, 34.0),
-                   (58.3, 36.8), (55.8, 43.3), (50.3, 45.9)],
-        vertices=[(28.1, 6.0), (28.1, 33.0), (44.0, 34.1), (57.8, 34.5), (57.8, 36.3), (55.3, 42.8)],
+        waypoints=[(27.8, 2.7), (27.6, 5.5), (27.6, 33.5), (44.5, 33.6), (47.2, 36.69507401175115),
+                   (55.8, 39.11309815931775), (55.8, 43.32261312113903), (50.3, 45.9)],
+        vertices=[(28.1, 6.0), (28.1, 33.0), (44.0, 34.1), (47.7, 36.2), (55.3, 39.6), (55.3, 42.8)],
     ),
 }
 
@@ -255,7 +256,7 @@ def scene_route(cfg: Config, scene: int) -> Route:
 # synthetic batches: the generator G(seed, B, cfg, scene) of SURVEY.md section 8d / BASELINE.md section 4
 # --------------------------------------------------------------------------------------------
 def synthetic_batch(cfg: Config, scene: int, B: int, seed: int, *, synthetic_circles: bool = False,
-                    random_dyn: bool = False):
+                    random_dyn: bool = False, routes=None):
     """-> P [B, n_p] float64: B independent instances at random points of a scene's route.
 
     Per instance: reference index idx ~ U{0..len-1}; state = reference sample
@@ -267,17 +268,23 @@ def synthetic_batch(cfg: Config, scene: int, B: int, seed: int, *, synthetic_cir
     ``synthetic_circles`` (BASELINE config 3): all Nobs slots are filled with vertices of random
     convex polygons scattered over a 60 x 60 m box, rejected within 1.0 m of the route.
     ``random_dyn`` (BASELINE config 4): per-instance random ellipses crossing the route.
+    ``routes``: a list of ``Route`` objects (e.g. ``frontend.random_routes``: randomised start/goal
+    pairs planned on the scene's polygons); each instance then draws its route uniformly.  Default:
+    the scene's own start -> end route.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
-    route = scene_route(cfg, scene)
+    route_list = list(routes) if routes else [scene_route(cfg, scene)]
+    route = route_list[0]
     N = cfg.N_hor
-    n = len(route.x_ref)
     P = np.empty((B, cfg.n_p), dtype=np.float64)
     circles = None
     if synthetic_circles:
         circles = _synthetic_circle_field(cfg, route, rng)
     pad_dyn = initial_dyn_constraints(cfg)
     for b in range(B):
+        if len(route_list) > 1:
+            route = route_list[int(rng.integers(0, len(route_list)))]
+        n = len(route.x_ref)
         idx = int(rng.integers(0, n))
         state = [route.x_ref[idx] + rng.normal(0, 0.05), route.y_ref[idx] + rng.normal(0, 0.05),
                  route.theta_ref[idx] + rng.normal(0, 0.1)]
