@@ -66,15 +66,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
+    force_dist = os.environ.get("NMPC_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path on a single GPU
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = named_config(args.config)
     B = args.batch
@@ -89,7 +92,8 @@ def main():
     d_u = torch.zeros(B, cfg.n_u, dtype=torch.float64, device=dev)
     d_y = torch.zeros(B, cfg.n1, dtype=torch.float64, device=dev)
     d_st = torch.zeros(B, 72, dtype=torch.uint8, device=dev)
-    d_gather = torch.empty(world * B, cfg.n_u, dtype=torch.float64, device=dev) if world > 1 else None
+    use_dist = dist is not None
+    d_gather = torch.empty(world * B, cfg.n_u, dtype=torch.float64, device=dev) if use_dist else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -100,12 +104,12 @@ def main():
         solver.solve_device(d_p, d_u, None, None, d_y, d_st)
         if i is not None:
             ev[i][1].record()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(d_gather, d_u)          # result gather over xGMI (RCCL)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -117,7 +121,7 @@ def main():
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -133,13 +137,15 @@ def main():
     bytes_alg = float(B * (8 * (cfg.n_p + 2 * cfg.n_u + cfg.n1) + 72))
     stats = np.array([st["num_inner_iterations"].sum(), st["num_outer_iterations"].sum(),
                       (st["exit_status"] == 0).sum(), B], dtype=np.float64)
-    if world > 1:
+    if use_dist:
         ts_ = torch.from_numpy(stats).to(dev)
         dist.all_reduce(ts_)
         stats = ts_.cpu().numpy()
 
+    if use_dist and world > 1:
+        assert torch.equal(d_gather[rank * B:(rank + 1) * B], d_u)      # own shard landed in its slot
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -194,7 +200,7 @@ def main():
                                "mean_inner_iters": float(sto["num_inner_iterations"].mean()),
                                "gpu_bitwise_equal_on_sample": same}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
