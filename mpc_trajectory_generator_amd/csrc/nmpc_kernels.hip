@@ -61,6 +61,7 @@ struct KArgs {
     double *y_out;
     nmpc_status *st;
     unsigned int *queue;
+    const int *order;          // queue position -> instance (longest-expected-first), or NULL = index order
     // eval kernel only
     const double *ev_c;
     const double *ev_y;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
             if (nxt >= (unsigned)a.B) {
                 done = true;
             } else {
-                inst = (int)nxt;
+                inst = a.order ? a.order[nxt] : (int)nxt;
                 prepare_instance<P>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
                 const double *u0 = a.u + (size_t)inst * a.n_u;
                 uv = in ? u0[2 * t] : 0.0;
@@ -760,6 +761,75 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 
 #include "nmpc_solve_dual.h"
 
+// ---------------------------------------------------------------------------------------------
+// launch-order heuristic.  Iteration counts are heavy-tailed and a batch ends when its slowest
+// instance does, so instances that LOOK hard are handed out first (list scheduling, longest expected
+// first).  "Looks hard" uses the inputs only: the reference samples of the horizon pass within
+// SCHED_CLEARANCE of a circle / ellipse, or the reference bends by more than SCHED_BEND inside
+// the horizon.  Only the order of processing changes; every instance's result is independent of it.
+// ---------------------------------------------------------------------------------------------
+namespace nmpc {
+constexpr double SCHED_CLEARANCE = 0.6;    // m
+constexpr double SCHED_BEND = 0.05;        // rad, summed |heading change| of the reference samples
+
+__global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
+    const double *p = a.p + (size_t)b * a.n_p;
+    const double *ps = p + NZ + N, *pd = ps + 3 * nobs, *pr = pd + 5 * ndyn * N;
+    bool hard = false;
+    double bend = 0.0;
+    for (int t = 0; t < N; ++t) {
+        const double rx = pr[3 * t], ry = pr[3 * t + 1];
+        if (t > 0) {
+            double d = pr[3 * t + 2] - pr[3 * t - 1];
+            d = d - 6.283185307179586 * rint(d * 0.15915494309189535);
+            bend += fabs(d);
+        }
+        for (int k = 0; k < nobs; ++k) {
+            const double r = ps[3 * k + 2];
+            if (r > 0.0) {
+                const double dx = rx - ps[3 * k], dy = ry - ps[3 * k + 1], lim = r + SCHED_CLEARANCE;
+                hard |= dx * dx + dy * dy < lim * lim;
+            }
+        }
+        for (int k = 0; k < ndyn; ++k) {
+            const double *e = pd + (k * N + t) * 5;
+            const double dx = rx - e[0], dy = ry - e[1], lim = fmax(e[2], e[3]) + SCHED_CLEARANCE;
+            hard |= dx * dx + dy * dy < lim * lim;
+        }
+    }
+    cls[b] = (hard || bend > SCHED_BEND) ? 1 : 0;
+}
+
+// stable partition of 0..B-1 by class (hard first); one block, deterministic
+__global__ void nmpc_order_kernel(int B, const unsigned char *cls, int *order)
+{
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int chunk = (B + nt - 1) / nt;
+    const int lo = t * chunk < B ? t * chunk : B, hi = lo + chunk < B ? lo + chunk : B;
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += cls[i];
+    cnt[t] = c;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {            // inclusive scan
+        const int v = t >= off ? cnt[t - off] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    const int total_hard = cnt[nt - 1];
+    int h = cnt[t] - c;                                  // hard instances before this chunk
+    int e = total_hard + (lo - h);                       // easy instances before this chunk, after all hard ones
+    for (int i = lo; i < hi; ++i) {
+        if (cls[i]) order[h++] = i; else order[e++] = i;
+    }
+}
+}  // namespace nmpc
+
 // =================================================================================================
 // C ABI (include/nmpc_solver.h)
 // =================================================================================================
@@ -776,6 +846,8 @@ struct nmpc_handle {
     int P;                 // lanes per instance
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
+    int *d_order;              // launch order (hard-looking instances first)
+    unsigned char *d_cls;
     // staging buffers of the host path
     double *d_p, *d_u, *d_y0, *d_c0, *d_yout, *d_psi, *d_grad, *d_F1, *d_F2;
     nmpc_status *d_st;
@@ -857,10 +929,14 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->P = pb->N <= 32 ? 32 : 64;
     h->map = make_map(*pb, op.lbfgs_memory);
     h->d_queue = nullptr;
+    h->d_order = nullptr;
+    h->d_cls = nullptr;
     h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
     h->d_st = nullptr;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_queue, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_order, sizeof(int) * (size_t)max_batch);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_cls, (size_t)max_batch);
     if (e != hipSuccess) { delete h; return NMPC_ERR_HIP; }
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, device_id);
@@ -880,7 +956,7 @@ void nmpc_free(nmpc_handle *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    hipFree(h->d_queue);
+    hipFree(h->d_queue); hipFree(h->d_order); hipFree(h->d_cls);
     hipFree(h->d_p); hipFree(h->d_u); hipFree(h->d_y0); hipFree(h->d_c0); hipFree(h->d_yout);
     hipFree(h->d_psi); hipFree(h->d_grad); hipFree(h->d_F1); hipFree(h->d_F2); hipFree(h->d_st);
     delete h;
@@ -914,6 +990,11 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     // one instance per wave: N_hor <= 32 runs the dual-evaluation kernel (two query points per
     // pass), longer horizons the one-point-per-pass kernel with the whole wave as one group
     const int grid = B < h->grid_cap ? B : h->grid_cap;
+    if (B > grid) {        // more instances than resident waves: hand the hard-looking ones out first
+        hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
+        hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
+        a.order = h->d_order;
+    }
 #ifdef NMPC_PROFILE
     const size_t lds = 4096 * 8 + 256;
 #else

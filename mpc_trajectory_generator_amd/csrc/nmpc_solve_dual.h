@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         if (lane == 0) nxt = atomicAdd(a.queue, 1u);
         nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
         if (nxt >= (unsigned)a.B) break;
-        const int inst = (int)nxt;
+        const int inst = a.order ? a.order[nxt] : (int)nxt;
 
         double vref;
         DynStage dyn;
@@ -282,6 +282,15 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
             // ================================================================ one pass: psi at two points
             double psi, pen, egv = 0, egw = 0, eav, eaw;
             n_pass++;
+            // Iteration counts are heavy-tailed: an instance that has already run long is likely the
+            // one the whole batch will end up waiting for.  Raise its wave's issue priority so that
+            // it runs at (nearly) single-wave speed while it still shares its SIMD with another wave.
+            if ((n_pass & 1023u) == 0u) {
+                const unsigned lvl = n_pass >> 11;
+                if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
+                else if (lvl == 2u) __builtin_amdgcn_s_setprio(2);
+                else if (lvl >= 3u) __builtin_amdgcn_s_setprio(3);
+            }
 #ifdef NMPC_PROFILE
             NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
 #endif
@@ -432,6 +441,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
 #endif
             a.st[inst] = s;
         }
+        __builtin_amdgcn_s_setprio(0);
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
     }
 }

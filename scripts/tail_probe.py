@@ -6,7 +6,8 @@ from mpc_trajectory_generator_amd.solver import BatchSolver
 from mpc_trajectory_generator_amd.harness import synthetic_batch
 cfg = named_config("cfg1")
 sol = BatchSolver(cfg, max_batch=8192)
-P = synthetic_batch(cfg, 11, 8192, 0)
+from mpc_trajectory_generator_amd.frontend import random_routes
+P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=1000))
 u, y, st = sol.solve(P)
 ps = st["reserved"].astype(np.int64)
 print("passes: mean", ps.mean(), "p50", np.median(ps), "p90", np.percentile(ps, 90), "p99", np.percentile(ps, 99), "max", ps.max(), "sum", ps.sum())
