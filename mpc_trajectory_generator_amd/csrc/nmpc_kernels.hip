@@ -207,30 +207,40 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     {
         const lds_double *sg = L + a.map.seg;
         const int nseg4 = (N - 1 + 3) & ~3;
-        for (int i = 0; i < nseg4; i += 4, sg += 4 * SEG_STRIDE) {
-            // all twenty LDS reads of the trip are issued before any arithmetic (the scheduling barrier
-            // keeps the compiler from sinking them next to their uses), then four independent chains run
-            double sd[4][5];
+        // software pipeline: the ten LDS reads of the NEXT pair of segments are issued before the current
+        // pair is reduced (the scheduling barriers keep the compiler from sinking them to their uses)
+        double cur[2][5], nxt[2][5];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int f = 0; f < 5; ++f) sd[j][f] = sg[j * SEG_STRIDE + f];
+            for (int f = 0; f < 5; ++f) cur[j][f] = sg[j * SEG_STRIDE + f];
+        for (int i = 0; i < nseg4; i += 2) {
+            sg += 2 * SEG_STRIDE;                           // table is padded: reading one pair past the end is safe
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int f = 0; f < 5; ++f) nxt[j][f] = sg[j * SEG_STRIDE + f];
             __builtin_amdgcn_sched_barrier(0);
-            double d2[4];
+            double d2[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double px = xn - sd[j][0], py = yn - sd[j][1];
-                const double dot = fma(px, sd[j][2], py * sd[j][3]);
-                const double that = dot * sd[j][4];
+            for (int j = 0; j < 2; ++j) {
+                const double px = xn - cur[j][0], py = yn - cur[j][1];
+                const double dot = fma(px, cur[j][2], py * cur[j][3]);
+                const double that = dot * cur[j][4];
                 const double tst = fmin(fmax(that, 0.0), 1.0);
-                const double ex = fma(tst, sd[j][2], -px), ey = fma(tst, sd[j][3], -py);
+                const double ex = fma(tst, cur[j][2], -px), ey = fma(tst, cur[j][3], -py);
                 d2[j] = fma(ex, ex, ey * ey);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                   // strict <: the first minimum keeps its index
+            for (int j = 0; j < 2; ++j) {                   // strict <: the first minimum keeps its index
                 bi = d2[j] < best ? i + j : bi;
                 best = fmin(best, d2[j]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int f = 0; f < 5; ++f) cur[j][f] = nxt[j][f];
         }
     }
     NMPC_EVTICK(1);     // stage cost + CTE loop
@@ -282,17 +292,25 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         }
         NMPC_EVTICK(5);     // static circle scan
         double dyh[NDYN_MAX];
+        {
+            double dv_[NDYN_MAX][DY_FIELDS];
 #pragma unroll
-        for (int k = 0; k < NDYN_MAX; ++k) {
-            dyh[k] = 0.0;
-            if (k < ndyn) {
-                const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
-                const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
-                const double ea = fma(dx, ca, dy * sa);
-                const double eb = fma(dx, sa, -(dy * ca));
-                const double h = fma(-(eb * eb), dyn.get(k, DY_IRY2), fma(-(ea * ea), dyn.get(k, DY_IRX2), 1.0));   // (:118)
-                dyh[k] = in ? fmax(h, 0.0) : 0.0;
-                m_dy |= (dyh[k] > 0.0 ? 1u : 0u) << k;
+            for (int k = 0; k < NDYN_MAX; ++k)
+#pragma unroll
+                for (int f = 0; f < DY_FIELDS; ++f) dv_[k][f] = k < ndyn ? dyn.get(k, f) : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NDYN_MAX; ++k) {
+                dyh[k] = 0.0;
+                if (k < ndyn) {
+                    const double ca = dv_[k][DY_CA], sa = dv_[k][DY_SA];
+                    const double dx = xn - dv_[k][DY_EX], dy = yn - dv_[k][DY_EY];
+                    const double ea = fma(dx, ca, dy * sa);
+                    const double eb = fma(dx, sa, -(dy * ca));
+                    const double h = fma(-(eb * eb), dv_[k][DY_IRY2], fma(-(ea * ea), dv_[k][DY_IRX2], 1.0));   // (:118)
+                    dyh[k] = in ? fmax(h, 0.0) : 0.0;
+                    m_dy |= (dyh[k] > 0.0 ? 1u : 0u) << k;
+                }
             }
         }
         NMPC_EVTICK(6);     // ellipse scan
@@ -897,7 +915,7 @@ static LdsMap make_map(const nmpc_problem &pb, int m)
     LdsMap mp;
     int o = 0;
     mp.sc = o;  o += 20;
-    mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 3);
+    mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
     mp.f2 = o;  o += 2 * (pb.nobs + pb.ndyn + 1);     // one F2 array per half (dual kernel)
     mp.rho = o; o += m;

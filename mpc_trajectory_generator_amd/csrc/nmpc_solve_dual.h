@@ -201,7 +201,28 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     }
                     // ---- d = H r, two-loop recursion over the tentative buffer ----
                     dv = rv; dw = rw;
-                    if (n_active > 0) {
+                    if (n_active == MAXMEM && m == MAXMEM) {
+                        // full buffer (the steady state): branch-free, all pairs addressed statically from the head
+                        double alpha[MAXMEM];
+                        const int tt = in ? t : 0;
+#pragma unroll
+                        for (int k = 0; k < MAXMEM; ++k) {
+                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
+                            const dbl2 s_ = ld_pair(LS, slot * N + tt, in), y_ = ld_pair(LY, slot * N + tt, in);
+                            const double al = Lrho[slot] * hdot<P>(s_.x, s_.y, dv, dw, lane);
+                            alpha[k] = al;
+                            dv = fma(-al, y_.x, dv); dw = fma(-al, y_.y, dw);
+                        }
+                        dv = n_H0 * dv; dw = n_H0 * dw;
+#pragma unroll
+                        for (int k = MAXMEM - 1; k >= 0; --k) {
+                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
+                            const dbl2 s_ = ld_pair(LS, slot * N + tt, in), y_ = ld_pair(LY, slot * N + tt, in);
+                            const double be = Lrho[slot] * hdot<P>(y_.x, y_.y, dv, dw, lane);
+                            const double ab = alpha[k] - be;
+                            dv = fma(ab, s_.x, dv); dw = fma(ab, s_.y, dw);
+                        }
+                    } else if (n_active > 0) {
                         // pair k lives in ring slot (n_head + k) mod m; each trip fetches the NEXT pair from
                         // LDS before it reduces the current one, so the LDS latency hides under the reduction
                         double alpha[MAXMEM];
