@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--routes", type=int, default=32,
                     help="randomised start/goal pairs planned on the scene (0: the scene's own start -> end route)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm", action="store_true",
+                    help="warm start: every step starts from the previous step's solution and multipliers "
+                         "(SURVEY.md section 8d second timing); the headline metric is the cold start")
     args = ap.parse_args()
 
     import torch
@@ -97,11 +100,16 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    d_y0 = torch.zeros(B, cfg.n1, dtype=torch.float64, device=dev) if args.warm else None
+
     def step(i=None):
-        d_u.zero_()                                   # cold start: u0 = 0 (the solver works in place)
+        if args.warm:
+            d_y0.copy_(d_y)                           # warm start: previous solution (in place) and multipliers
+        else:
+            d_u.zero_()                               # cold start: u0 = 0 (the solver works in place)
         if i is not None:
             ev[i][0].record()
-        solver.solve_device(d_p, d_u, None, None, d_y, d_st)
+        solver.solve_device(d_p, d_u, d_y0, None, d_y, d_st)
         if i is not None:
             ev[i][1].record()
         if use_dist:
@@ -157,7 +165,7 @@ def main():
         "config": {"workload": f"{args.config}: default.yaml-shaped NMPC, N_hor={cfg.N_hor}, Nobs={cfg.Nobs}, "
                                f"Ndynobs={cfg.Ndynobs}, scene {args.scene} ({args.routes or 1} route(s): "
                                f"{'randomised start/goal planned by the visibility-graph front-end' if args.routes else 'scene start->end'}), "
-                               f"batch={B}/GPU, cold start (u0=0, y0=0, c0=1), "
+                               f"batch={B}/GPU, {'WARM start (previous solution and multipliers, c0=1)' if args.warm else 'cold start (u0=0, y0=0, c0=1)'}, "
                                f"tol 1e-4, caps inner {solver.opts.max_inner}/outer {solver.opts.max_outer}",
                    "batch_per_gpu": B, "n_u": cfg.n_u, "n_p": cfg.n_p, "parallelism": f"instance-sharded x{world}"},
         "mean_inner_iters": stats[0] / stats[3], "mean_outer_iters": stats[1] / stats[3],
@@ -177,7 +185,7 @@ def main():
                          "traffic_source": "profiles/r01/pmc_fetch.csv + pmc_write.csv (separate --pmc passes)"},
     }
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not args.warm:
         # CPU leg: the oracle on the host cores, bounded sample of the same batch (rank 0, any N)
         from oracle import Oracle
         orc = Oracle(cfg.N_hor, cfg.Nobs, cfg.Ndynobs, cfg.ts, cfg.lin_vel_min, cfg.lin_vel_max, cfg.ang_vel_max,
