@@ -93,7 +93,7 @@ typedef struct nmpc_status {
     uint32_t num_inner_iterations;
     uint32_t num_cost_evals;         /* forward-only evaluations of psi             */
     uint32_t num_grad_evals;         /* forward + adjoint evaluations               */
-    uint32_t reserved;
+    uint32_t reserved;               /* diagnostic: evaluation passes the kernel executed         */
     double last_problem_norm_fpr;
     double delta_y_norm_over_c;
     double f2_norm;

@@ -1077,23 +1077,28 @@ int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, con
     int rc = ensure_staging(h);
     if (rc) return rc;
     const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb);
-    hipEvent_t e0, e1;
-    HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipMemcpy(h->d_p, p, B * np * 8, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_u, u, B * nu * 8, hipMemcpyHostToDevice));
     if (y0) HIP_TRY(h, hipMemcpy(h->d_y0, y0, B * n1 * 8, hipMemcpyHostToDevice));
     if (c0) HIP_TRY(h, hipMemcpy(h->d_c0, c0, B * 8, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipEventRecord(e0, nullptr));
-    rc = nmpc_solve_batch_device(h, B, h->d_p, h->d_u, y0 ? h->d_y0 : nullptr, c0 ? h->d_c0 : nullptr,
-                                 h->d_yout, h->d_st, nullptr);
-    if (rc) return rc;
-    HIP_TRY(h, hipEventRecord(e1, nullptr));
-    HIP_TRY(h, hipDeviceSynchronize());
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, nullptr);
+    if (he == hipSuccess) {
+        rc = nmpc_solve_batch_device(h, B, h->d_p, h->d_u, y0 ? h->d_y0 : nullptr, c0 ? h->d_c0 : nullptr,
+                                     h->d_yout, h->d_st, nullptr);
+        if (rc == NMPC_OK) {
+            he = hipEventRecord(e1, nullptr);
+            if (he == hipSuccess) he = hipDeviceSynchronize();
+            if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (he != hipSuccess) return fail(h, NMPC_ERR_HIP, "solve_batch_host", he);
     HIP_TRY(h, hipMemcpy(u, h->d_u, B * nu * 8, hipMemcpyDeviceToHost));
     if (y_out) HIP_TRY(h, hipMemcpy(y_out, h->d_yout, B * n1 * 8, hipMemcpyDeviceToHost));
     if (status) {
