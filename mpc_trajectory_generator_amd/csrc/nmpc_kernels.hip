@@ -12,6 +12,7 @@
 
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -964,6 +965,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     // the register budget (2 waves per SIMD)
     int per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
     if (per_cu > 8) per_cu = 8;
+    if (const char *env = getenv("NMPC_WAVES_PER_CU")) {       // tuning knob (experiments only)
+        const int v = atoi(env);
+        if (v >= 1 && v <= per_cu) per_cu = v;
+    }
     if (per_cu < 1) per_cu = 1;
     h->grid_cap = prop.multiProcessorCount * per_cu;
     *out = h;
