@@ -176,3 +176,17 @@ def test_vectorized_receding_horizon_equals_loop_version():
         Pv, _ = vec.step(solve)
         assert np.array_equal(Pl, Pv), (k, np.argwhere(Pl != Pv)[:5])
     assert np.array_equal(vec.state, np.array([s[-3:] for s in loop.states]))
+
+
+def test_report_counterparts():
+    from mpc_trajectory_generator_amd.report import batch_summary, loop_time_histogram, runtime_analysis
+    txt = runtime_analysis({"opt_launch": 12, "mpc_time": 3400, "solver_time": 2900.5, "total_time": 3500}, [20.0, 30.0, 25.0], [1.0, 2.0, 1.5])
+    assert "Solver calls" in txt and "Mean solver time" in txt and "25.000" in txt
+    counts, edges = loop_time_histogram([20.0, 30.0, 25.0], [1.0, 2.0, 1.5], bins=3)
+    assert counts.sum() == 3 and len(edges) == 4
+    from oracle.binding import STATUS_DTYPE
+    st = np.zeros(4, dtype=STATUS_DTYPE)
+    st["num_inner_iterations"] = [10, 20, 30, 40]
+    st["exit_status"] = [0, 0, 1, 0]
+    s = batch_summary(st)
+    assert s["converged_frac"] == 0.75 and s["max_inner_iters"] == 40 and s["exit_status_counts"] == {0: 3, 1: 1}
