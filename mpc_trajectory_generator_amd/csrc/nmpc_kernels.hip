@@ -321,15 +321,21 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             const unsigned u_lo = wave_or(m_lo), u_hi = nobs > 32 ? wave_or(m_hi) : 0u;
             act = ((unsigned long long)u_hi << 32) | u_lo;
             act_dyn = ndyn > 0 ? wave_or(m_dy) : 0u;
-            for (unsigned long long rem = act; rem;) {
-                const int k = __builtin_ctzll(rem);
+            for (unsigned long long rem = act; rem;) {      // two touched circles per trip: their tree sums interleave
+                const int k0 = __builtin_ctzll(rem);
                 rem &= rem - 1;
-                const lds_double *o1 = L + a.map.obs + 3 * k;
-                const double dx = xn - o1[0], dy = yn - o1[1];
-                const double h = fma(-dy, dy, fma(-dx, dx, o1[2]));
-                const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
-                if (t == 0) L[f2off + k] = f2;
-                pen = fma(f2, f2, pen);
+                const bool two = rem != 0ull;
+                const int k1 = two ? __builtin_ctzll(rem) : k0;
+                rem &= rem - (two ? 1ull : 0ull);
+                const lds_double *o0 = L + a.map.obs + 3 * k0, *o1 = L + a.map.obs + 3 * k1;
+                const double ax = o0[0], ay = o0[1], ar = o0[2], bx = o1[0], by = o1[1], br = o1[2];
+                const double dx0 = xn - ax, dy0 = yn - ay, dx1 = xn - bx, dy1 = yn - by;
+                const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar)), h1 = fma(-dy1, dy1, fma(-dx1, dx1, br));
+                const double f20 = group_sum<P>(in ? fmax(h0, 0.0) : 0.0, lane);
+                const double f21 = group_sum<P>(in ? fmax(h1, 0.0) : 0.0, lane);
+                if (t == 0) { L[f2off + k0] = f20; if (two) L[f2off + k1] = f21; }
+                pen = fma(f20, f20, pen);
+                if (two) pen = fma(f21, f21, pen);
             }
 #pragma unroll
             for (int k = 0; k < NDYN_MAX; ++k) {
