@@ -226,3 +226,47 @@ def test_non_finite_inputs_are_contained(solvers):
     if not r.is_ok():
         assert r.get().code == 2000
     mng.kill()
+
+
+def test_closed_loop_scene11_with_own_frontend():
+    """End to end: plan on scene 11's polygons, drive the robot to the goal through the HIP solver."""
+    from mpc_trajectory_generator_amd import harness
+    from mpc_trajectory_generator_amd.frontend import scene_planner
+    from mpc_trajectory_generator_amd.trajectory import TrajectoryGenerator
+    cfg = named_config("cfg1")
+    s = harness.SCENES[11]
+    route = scene_planner(cfg, 11).route(s["start"], s["end"])
+    out = TrajectoryGenerator(cfg).run(route, max_steps=600)
+    assert out is not None
+    xx, xy, uv, uw = out[:4]
+    assert abs(xx[-1] - s["end"][0]) <= 0.05 and abs(xy[-1] - s["end"][1]) <= 0.05 and abs(uv[-1]) < 0.005
+    assert max(uv) <= cfg.lin_vel_max + 1e-12 and max(abs(w) for w in uw) <= cfg.ang_vel_max + 1e-12
+    acc = np.diff(np.array([0.0] + list(uv))) / cfg.ts
+    assert acc.max() <= cfg.lin_acc_max + 5e-3 and acc.min() >= cfg.lin_acc_min - 5e-3      # ALM constraint, delta 1e-4 on ||dy||/c
+    for vx, vy in route.vertices:
+        assert np.min(np.hypot(np.array(xx) - vx, np.array(xy) - vy)) > 0.4
+
+
+def test_batched_receding_horizon_on_gpu_equals_oracle(solvers):
+    """Config-4 style lock-step batch: HIP and oracle driven through the same vectorised assembly give
+    identical parameter vectors and states step after step (warm starts carried)."""
+    from mpc_trajectory_generator_amd import harness
+    from mpc_trajectory_generator_amd.trajectory import VectorizedRecedingHorizon
+    cfg = named_config("cfg4")
+    s, o = solvers("cfg4"), oracle_for(cfg)
+    route = harness.scene_route(cfg, 1)
+    rng = np.random.default_rng(5)
+    B, n = 12, len(route.x_ref)
+    i0 = rng.integers(0, n - 30, B)
+    starts = np.stack([np.array(route.x_ref)[i0] + rng.normal(0, 0.05, B), np.array(route.y_ref)[i0] + rng.normal(0, 0.05, B),
+                       np.array(route.theta_ref)[i0]], axis=1)
+    c = np.stack([np.array(route.x_ref)[i0 + 8], np.array(route.y_ref)[i0 + 8]], axis=1)[:, None, :].repeat(3, axis=1)
+    dyn = (c + rng.uniform(-3, 3, (B, 3, 2)), c + rng.uniform(-3, 3, (B, 3, 2)), rng.uniform(0.05, 0.1, (B, 3)),
+           rng.uniform(0.3, 1.0, (B, 3)), rng.uniform(0.3, 1.0, (B, 3)), rng.uniform(0, np.pi, (B, 3)))
+    a, b = VectorizedRecedingHorizon(route, starts, dyn), VectorizedRecedingHorizon(route, starts, dyn)
+    a.idx, b.idx = i0.astype(np.int64), i0.astype(np.int64)
+    for k in range(5):
+        Pa, sta = a.step(lambda P, U, Y: s.solve(P, u0=U, y0=Y))
+        Pb, stb = b.step(lambda P, U, Y: o.solve_batch(P, u0=U, y0=Y, threads=8))
+        assert np.array_equal(Pa, Pb) and np.array_equal(a.state, b.state)
+        assert np.array_equal(sta["num_inner_iterations"], stb["num_inner_iterations"])
