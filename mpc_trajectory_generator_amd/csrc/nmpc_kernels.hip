@@ -826,31 +826,35 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
             hard |= dx * dx + dy * dy < lim * lim;
         }
     }
-    cls[b] = (hard || bend > SCHED_BEND) ? 1 : 0;
+    cls[b] = (unsigned char)((hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0));      // 2: both, 1: one of them, 0: neither
 }
 
-// stable partition of 0..B-1 by class (hard first); one block, deterministic
+// stable three-way partition of 0..B-1 by class (2, then 1, then 0); one block, deterministic
 __global__ void nmpc_order_kernel(int B, const unsigned char *cls, int *order)
 {
-    __shared__ int cnt[1024];
+    __shared__ int cnt2[1024], cnt1[1024];
     const int t = threadIdx.x, nt = blockDim.x;
     const int chunk = (B + nt - 1) / nt;
     const int lo = t * chunk < B ? t * chunk : B, hi = lo + chunk < B ? lo + chunk : B;
-    int c = 0;
-    for (int i = lo; i < hi; ++i) c += cls[i];
-    cnt[t] = c;
+    int c2 = 0, c1 = 0;
+    for (int i = lo; i < hi; ++i) { c2 += cls[i] == 2; c1 += cls[i] == 1; }
+    cnt2[t] = c2;
+    cnt1[t] = c1;
     __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {            // inclusive scan
-        const int v = t >= off ? cnt[t - off] : 0;
+    for (int off = 1; off < nt; off <<= 1) {            // inclusive scans
+        const int v2 = t >= off ? cnt2[t - off] : 0, v1 = t >= off ? cnt1[t - off] : 0;
         __syncthreads();
-        cnt[t] += v;
+        cnt2[t] += v2;
+        cnt1[t] += v1;
         __syncthreads();
     }
-    const int total_hard = cnt[nt - 1];
-    int h = cnt[t] - c;                                  // hard instances before this chunk
-    int e = total_hard + (lo - h);                       // easy instances before this chunk, after all hard ones
+    const int total2 = cnt2[nt - 1], total1 = cnt1[nt - 1];
+    int p2 = cnt2[t] - c2;                               // class-2 instances before this chunk
+    int p1 = total2 + (cnt1[t] - c1);                    // class-1 instances go after all of class 2
+    int p0 = total2 + total1 + (lo - (cnt2[t] - c2) - (cnt1[t] - c1));
     for (int i = lo; i < hi; ++i) {
-        if (cls[i]) order[h++] = i; else order[e++] = i;
+        const int c = cls[i];
+        if (c == 2) order[p2++] = i; else if (c == 1) order[p1++] = i; else order[p0++] = i;
     }
 }
 }  // namespace nmpc
