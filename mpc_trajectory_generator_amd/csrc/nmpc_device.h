@@ -1,7 +1,7 @@
 // nmpc_device.h -- device-side building blocks of the batched NMPC solver (gfx950 / CDNA4 only).
 //
-// Mapping: one wavefront (64 lanes) = one workgroup.  A problem instance owns a GROUP of P lanes
-// (P = 32 for N_hor <= 32 -> two instances per wave; P = 64 otherwise), lane t of the group owns
+// Mapping: one wavefront (64 lanes) = one workgroup.  A query point owns a GROUP of lanes (P = 20:
+// three groups per wave for N_hor <= 20; P = 32: two groups; P = 64: one), lane t of the group owns
 // stage t of the horizon: its control pair (v_t, w_t), its post-update state (x_{t+1}, y_{t+1},
 // theta_{t+1}) and the adjoints of both.  Everything that is uniform over an instance lives in the
 // group's LDS slice; horizon sums / scans are cross-lane operations inside the group.
@@ -140,6 +140,92 @@ __device__ __forceinline__ double from_next(double v, int lane)
 {
     const double o = dpp_mov<0x130>(v);         // wave_shl:1
     return (lane & (P - 1)) == P - 1 ? 0.0 : o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lane <-> (group, stage) mapping.  P = 32 / 64: groups of P consecutive lanes.
+// P = 20 is the THREE-groups-per-wave layout for N_hor <= 20 ("tri"): group q = 0..2 owns row q of the
+// wave (lanes 16q..16q+15, stages 0..15) plus quad q of row 3 (lanes 48+4q..51+4q, stages 16..19);
+// lanes 60..63 are stages 20..23 of group 2: beyond the horizon like stages N..31 of a P = 32 group
+// (their vectors are zero, the group's scalars reach them), with LDS columns of their own.
+// ---------------------------------------------------------------------------------------------
+template <int P> __device__ __forceinline__ int lay_group(int lane) { return lane / P; }
+template <int P> __device__ __forceinline__ int lay_stage(int lane) { return lane % P; }
+template <int P> constexpr int lay_cols() { return P == 20 ? 24 : P; }      // per-stage LDS columns of a group
+template <> __device__ __forceinline__ int lay_group<20>(int lane)
+{
+    return lane < 48 ? lane >> 4 : (lane < 60 ? (lane - 48) >> 2 : 2);
+}
+template <> __device__ __forceinline__ int lay_stage<20>(int lane)
+{
+    return lane < 48 ? lane & 15 : (lane < 60 ? 16 + (lane & 3) : 20 + (lane & 3));
+}
+// lane that holds stage t (< N_hor) of group q
+template <int P> __device__ __forceinline__ int lay_lane(int q, int t) { return q * P + t; }
+template <> __device__ __forceinline__ int lay_lane<20>(int q, int t) { return t < 16 ? 16 * q + t : 48 + 4 * q + (t - 16); }
+
+// The tri layout computes the SAME canonical tree / scans as P = 32 with stages 20..31 absent (they
+// are zero there): levels 1, 2 run in quads everywhere, levels 4, 8 only in rows 0..2 (the tail
+// quads add 0.0, as the zero padding does), and the row <-> tail exchange is one ds_bpermute.
+template <>
+__device__ __forceinline__ double group_sum<20>(double v, int lane)
+{
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    {   // lanes 60..63 (stages 20..23 of group 2) take the sum of the group's tail quad: row_shr:4 into bank 3 of row 3
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x114, 0x8, 0x8, false);
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x114, 0x8, 0x8, false);
+        v = __hiloint2double(hi, lo);
+    }
+    v = v + dpp_mov<0x141, 0x7>(v);         // rows 0..2 only; row 3 adds 0.0
+    v = v + dpp_mov<0x140, 0x7>(v);
+    const int q = lay_group<20>(lane);
+    const int partner = lane < 48 ? 48 + 4 * q : 16 * q;
+    return v + lane_get(v, partner);        // block 0 + block 1 (commutative: same bits on both sides)
+}
+
+template <>
+__device__ __forceinline__ double group_prefix<20>(double v, int lane)
+{
+    const bool tail = lane >= 48;
+    double o = dpp_mov<0x111>(v);
+    v = v + ((tail && (lane & 3) < 1) ? 0.0 : o);
+    o = dpp_mov<0x112>(v);
+    v = v + ((tail && (lane & 3) < 2) ? 0.0 : o);
+    v = v + dpp_mov<0x114, 0x7>(v);
+    v = v + dpp_mov<0x118, 0x7>(v);
+    const int q = (lane - 48) >> 2;
+    const double carry = lane_get(v, (tail && lane < 60) ? 16 * q + 15 : lane);     // last entry of block 0
+    return v + (tail ? carry : 0.0);
+}
+
+template <>
+__device__ __forceinline__ double group_suffix<20>(double v, int lane)
+{
+    const bool tail = lane >= 48;
+    double o = dpp_mov<0x101>(v);
+    v = v + ((tail && (lane & 3) > 2) ? 0.0 : o);
+    o = dpp_mov<0x102>(v);
+    v = v + ((tail && (lane & 3) > 1) ? 0.0 : o);
+    v = v + dpp_mov<0x104, 0x7>(v);
+    v = v + dpp_mov<0x108, 0x7>(v);
+    const double carry = lane_get(v, tail ? lane : 48 + 4 * (lane >> 4));            // first entry of block 1
+    return v + (tail ? 0.0 : carry);
+}
+
+template <>
+__device__ __forceinline__ double from_prev<20>(double v, int lane, double fill)
+{
+    const int src = (lane >= 48 && (lane & 3) == 0) ? (lane < 60 ? 16 * ((lane - 48) >> 2) + 15 : lane) : lane - 1;
+    const double o = lane_get(v, src);
+    return (lane < 48 && (lane & 15) == 0) ? fill : o;
+}
+template <>
+__device__ __forceinline__ double from_next<20>(double v, int lane)
+{
+    const int src = (lane < 48 && (lane & 15) == 15) ? 48 + 4 * (lane >> 4) : lane + 1;
+    const double o = lane_get(v, src);
+    return (lane >= 48 && (lane & 3) == 3) ? 0.0 : o;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -116,7 +116,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     {
         lds_double *col = L + a.map.dyn + t;
         dyn.col = col;
-        dyn.stride = P;
+        dyn.stride = lay_cols<P>();
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
             double ex = 0.0, ey = 0.0, ca = 0.0, sa = 0.0, irx2 = 1.0, iry2 = 1.0;
@@ -128,12 +128,12 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
                 iry2 = 1.0 / (e[3] * e[3]);
                 sincos_cw(e[4], sa, ca);
             }
-            col[(k * DY_FIELDS + DY_EX) * P] = ex;
-            col[(k * DY_FIELDS + DY_EY) * P] = ey;
-            col[(k * DY_FIELDS + DY_CA) * P] = ca;
-            col[(k * DY_FIELDS + DY_SA) * P] = sa;
-            col[(k * DY_FIELDS + DY_IRX2) * P] = irx2;
-            col[(k * DY_FIELDS + DY_IRY2) * P] = iry2;
+            col[(k * DY_FIELDS + DY_EX) * lay_cols<P>()] = ex;
+            col[(k * DY_FIELDS + DY_EY) * lay_cols<P>()] = ey;
+            col[(k * DY_FIELDS + DY_CA) * lay_cols<P>()] = ca;
+            col[(k * DY_FIELDS + DY_SA) * lay_cols<P>()] = sa;
+            col[(k * DY_FIELDS + DY_IRX2) * lay_cols<P>()] = irx2;
+            col[(k * DY_FIELDS + DY_IRY2) * lay_cols<P>()] = iry2;
         }
     }
     const double *pr = pd + 5 * ndyn * N;
@@ -441,26 +441,27 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
 {
     extern __shared__ double lds[];
     constexpr int K = 64 / P;
-    const int lane = threadIdx.x, g = lane / P, t = lane % P;
+    const int lane = threadIdx.x, g = lay_group<P>(lane), t = lay_stage<P>(lane);
     lds_double *L = (lds_double *)lds + g * a.map.total;
     const int N = a.pb.N;
+    const bool in = t < N;
     const int inst = blockIdx.x * K + g;
     const int b = inst < a.B ? inst : a.B - 1;          // surplus groups redo the last instance, write nothing
     double vref;
     DynStage dyn;
     prepare_instance<P>(a, L, a.p + (size_t)b * a.n_p, t, vref, dyn);
     const double *u = a.u + (size_t)b * a.n_u;
-    const double zv = t < N ? u[2 * t] : 0.0, zw = t < N ? u[2 * t + 1] : 0.0;
+    const double zv = in ? u[2 * t] : 0.0, zw = in ? u[2 * t + 1] : 0.0;
     const double c = a.ev_c ? a.ev_c[b] : 0.0;
-    const double yv = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + t] : 0.0;
-    const double yw = (a.ev_y && t < N) ? a.ev_y[(size_t)b * a.n1 + N + t] : 0.0;
+    const double yv = (a.ev_y && in) ? a.ev_y[(size_t)b * a.n1 + t] : 0.0;
+    const double yw = (a.ev_y && in) ? a.ev_y[(size_t)b * a.n1 + N + t] : 0.0;
     for (int k = t; k < a.n2; k += P) L[a.map.f2 + k] = 0.0;
     NMPC_WAVE_SYNC();
     double psi, pen, gv, gw, av, aw;
     eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, c, 1.0 / fmax(c, 1.0), yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
     if (inst >= a.B) return;
     if (t == 0 && a.ev_psi) a.ev_psi[b] = psi;
-    if (t < N) {
+    if (in) {
         if (a.ev_grad) { a.ev_grad[(size_t)b * a.n_u + 2 * t] = gv; a.ev_grad[(size_t)b * a.n_u + 2 * t + 1] = gw; }
         if (a.ev_F1) { a.ev_F1[(size_t)b * a.n1 + t] = av; a.ev_F1[(size_t)b * a.n1 + N + t] = aw; }
     }
@@ -785,6 +786,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 }  // namespace nmpc
 
 #include "nmpc_solve_dual.h"
+#include "nmpc_solve_tri.h"
 
 // ---------------------------------------------------------------------------------------------
 // launch-order heuristic.  Iteration counts are heavy-tailed and a batch ends when its slowest
@@ -921,18 +923,19 @@ static int fail(nmpc_handle *h, int code, const char *what, hipError_t e = hipSu
         if (e_ != hipSuccess) return fail((h), NMPC_ERR_HIP, #call, e_);       \
     } while (0)
 
-static LdsMap make_map(const nmpc_problem &pb, int m)
+static LdsMap make_map(const nmpc_problem &pb, int m, int P)
 {
     LdsMap mp;
     int o = 0;
     mp.sc = o;  o += 20;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
-    mp.f2 = o;  o += 2 * (pb.nobs + pb.ndyn + 1);     // one F2 array per half (dual kernel)
+    mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / tri kernels)
     mp.rho = o; o += m;
-    mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * (pb.N <= 32 ? 32 : 64);
+    const int cols = P == 20 ? 24 : P;                // nmpc::lay_cols
+    mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * cols;
     o = (o + 1) & ~1;
-    mp.vec = o; o += 4 * 2 * (pb.N <= 32 ? 32 : 64);
+    mp.vec = o; o += 4 * 2 * cols;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
     mp.S = o;   o += 2 * pb.N * m;
     mp.Y = o;   o += 2 * pb.N * m;
@@ -955,8 +958,11 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         return NMPC_ERR_NO_DEVICE;
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true;
-    h->P = pb->N <= 32 ? 32 : 64;
-    h->map = make_map(*pb, op.lbfgs_memory);
+    h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : 64);
+    if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments: force the two-point layout
+        if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
+    }
+    h->map = make_map(*pb, op.lbfgs_memory, h->P);
     h->d_queue = nullptr;
     h->d_order = nullptr;
     h->d_cls = nullptr;
@@ -969,7 +975,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (e != hipSuccess) { delete h; return NMPC_ERR_HIP; }
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, device_id);
-    const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * 2;       // eval kernel: two slices per wave
+    const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * (64 / h->P);   // eval kernel: one slice per group
     if (lds_bytes > 160 * 1024) { hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
     // the solve kernels use one LDS slice per wave; resident waves per CU are bounded by LDS and by
     // the register budget (2 waves per SIMD)
@@ -1033,7 +1039,8 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
-    if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
+    if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
@@ -1056,7 +1063,8 @@ int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const doubl
     const int K = 64 / h->P;
     const int grid = (B + K - 1) / K;
     const size_t lds = (size_t)h->map.total * sizeof(double) * K;
-    if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<32>, dim3(grid), dim3(64), lds, s, a);
+    if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<20>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<32>, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
