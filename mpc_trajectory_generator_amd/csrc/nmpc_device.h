@@ -231,24 +231,44 @@ __device__ __forceinline__ double from_next<20>(double v, int lane)
 // ---------------------------------------------------------------------------------------------
 // sin and cos: Cody-Waite reduction by pi/2 in three fma steps + fdlibm minimax kernels (Horner, fma)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sincos_cw(double x, double &s, double &c)
+// The ten coefficients that enter a Horner step as the ADDEND can be read from a table in LDS
+// (`tab`, filled from CW_COEF_DEV): as literals the compiler keeps them in twenty long-lived VGPRs
+// (and copies them before every v_fmac); as LDS operands they are transient.
+constexpr int CW_NCOEF = 10;
+#define NMPC_CW_COEFS                                                                              \
+    -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04,           \
+    8.33333333332248946124e-03, -1.66666666666666324348e-01, 2.08757232129817482790e-09,            \
+    -2.75573143513906633035e-07, 2.48015872894767294178e-05, -1.38888888888741095749e-03,           \
+    4.16666666666666019037e-02
+__device__ const double CW_COEF_DEV[CW_NCOEF] = {NMPC_CW_COEFS};
+struct CwLiteral {
+    __device__ __forceinline__ double operator[](int i) const
+    {
+        constexpr double k[CW_NCOEF] = {NMPC_CW_COEFS};
+        return k[i];
+    }
+};
+#undef NMPC_CW_COEFS
+
+template <class TAB>
+__device__ __forceinline__ void sincos_cw_t(double x, TAB tab, double &s, double &c)
 {
     const double k = rint(x * 6.36619772367581382433e-01);
     double r = fma(-k, 1.57079632673412561417e+00, x);
     r = fma(-k, 6.07710050630396597660e-11, r);
     r = fma(-k, 2.02226624879595063154e-21, r);
     const double z = r * r;
-    double ps = fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
+    double ps = fma(1.58969099521155010221e-10, z, tab[0]);
+    ps = fma(ps, z, tab[1]);
+    ps = fma(ps, z, tab[2]);
+    ps = fma(ps, z, tab[3]);
+    ps = fma(ps, z, tab[4]);
     const double sr = fma(r * z, ps, r);
-    double pc = fma(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
+    double pc = fma(-1.13596475577881948265e-11, z, tab[5]);
+    pc = fma(pc, z, tab[6]);
+    pc = fma(pc, z, tab[7]);
+    pc = fma(pc, z, tab[8]);
+    pc = fma(pc, z, tab[9]);
     const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
     const int n = ((int)k) & 3;
     double so = (n & 1) ? cr : sr;
@@ -258,6 +278,7 @@ __device__ __forceinline__ void sincos_cw(double x, double &s, double &c)
     s = so;
     c = co;
 }
+__device__ __forceinline__ void sincos_cw(double x, double &s, double &c) { sincos_cw_t(x, CwLiteral(), s, c); }
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 

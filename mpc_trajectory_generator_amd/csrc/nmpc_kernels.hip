@@ -38,6 +38,7 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 // LDS slice of one group (offsets in doubles)
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
+    int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
@@ -93,16 +94,27 @@ struct DynStage {
     __device__ __forceinline__ double get(int k, int f) const { return col[(k * DY_FIELDS + f) * stride]; }
 };
 
+// Problem shape known at compile time (0 / -1: taken from the arguments at run time).  The reference
+// generates one solver per configuration (mpc_generator.py:173-193); ShapeDefault is the shape of
+// configs/default.yaml (N_hor 20, Nobs 10, Ndynobs 3), for which loops unroll and LDS offsets fold.
+struct ShapeAny { static constexpr int N = 0, NOBS = -1, NDYN = -1; };
+struct ShapeDefault { static constexpr int N = 20, NOBS = 10, NDYN = 3; };
+template <class SH> __device__ __forceinline__ int shape_N(const KArgs &a) { if constexpr (SH::N > 0) return SH::N; else return a.pb.N; }
+template <class SH> __device__ __forceinline__ int shape_nobs(const KArgs &a) { if constexpr (SH::NOBS >= 0) return SH::NOBS; else return a.pb.nobs; }
+template <class SH> __device__ __forceinline__ int shape_ndyn(const KArgs &a) { if constexpr (SH::NDYN >= 0) return SH::NDYN; else return a.pb.ndyn; }
+
 // ---------------------------------------------------------------------------------------------
 // instance set-up: p -> LDS slice + per-lane registers     (reference mpc_generator.py:73-79,93-104,127-136)
 // ---------------------------------------------------------------------------------------------
-template <int P>
+template <int P, class SH = ShapeAny>
 __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, const double *p, int t,
                                                  double &vref, DynStage &dyn)
 {
-    const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
+    const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     if (t < 8) L[a.map.sc + t] = p[t];                      // state, last input, target (p[8:10] unused)
     if (t >= 8 && t < 18) L[a.map.sc + t] = p[t + 2];       // ten weights p[10:20]
+    if (t < CW_NCOEF) L[a.map.cw + t] = CW_COEF_DEV[t];
+    NMPC_WAVE_SYNC();
     vref = t < N ? p[NZ + t] : 0.0;
     const double *ps = p + NZ + N;
     for (int k = t; k < ((nobs + 3) & ~3); k += P) {       // padded to a multiple of 4 with inert zero circles
@@ -126,7 +138,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
                 ey = e[1];
                 irx2 = 1.0 / (e[2] * e[2]);
                 iry2 = 1.0 / (e[3] * e[3]);
-                sincos_cw(e[4], sa, ca);
+                sincos_cw_t(e[4], (const lds_double *)(L + a.map.cw), sa, ca);
             }
             col[(k * DY_FIELDS + DY_EX) * lay_cols<P>()] = ex;
             col[(k * DY_FIELDS + DY_EY) * lay_cols<P>()] = ey;
@@ -159,16 +171,18 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
 #ifdef NMPC_PROFILE
 #define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_evt[i] += t_ - nmpc_evl; nmpc_evl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ long long nmpc_dummy_;
+#elif defined(NMPC_MARKS)       // scripts/isa_stats.py: section markers in the ISA dump
+#define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define NMPC_EVTICK(i) do { } while (0)
 #endif
-template <int P>
+template <int P, class SH = ShapeAny>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
                                          double &gw, double &av_out, double &aw_out)
 {
-    const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
+    const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
     const bool in = t < N;
 #ifdef NMPC_PROFILE
@@ -184,7 +198,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const double thn = fma(ts, group_prefix<P>(zw, lane), th0);
     const double th = from_prev<P>(thn, lane, th0);
     double sn, cs;
-    sincos_cw(th, sn, cs);
+    sincos_cw_t(th, (const lds_double *)(L + a.map.cw), sn, cs);
     const double xn = fma(ts, group_prefix<P>(zv * cs, lane), x0);
     const double yn = fma(ts, group_prefix<P>(zv * sn, lane), y0);
     const double xp = from_prev<P>(xn, lane, x0);
@@ -215,6 +229,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int f = 0; f < 5; ++f) cur[j][f] = sg[j * SEG_STRIDE + f];
+#pragma unroll(SH::N > 0 ? 32 : 1)
         for (int i = 0; i < nseg4; i += 2) {
             sg += 2 * SEG_STRIDE;                           // table is padded: reading one pair past the end is safe
 #pragma unroll
@@ -277,6 +292,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     {
         const lds_double *ob = L + a.map.obs;
         const int nobs4 = (nobs + 3) & ~3;
+#pragma unroll(SH::NOBS >= 0 ? 16 : 1)
         for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, VALU only
             double od[12];
 #pragma unroll
@@ -874,7 +890,8 @@ struct nmpc_handle {
     int max_batch;
     bool alive;
     LdsMap map;
-    int P;                 // lanes per instance
+    int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one)
+    bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
     int *d_order;              // launch order (hard-looking instances first)
@@ -928,6 +945,7 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     LdsMap mp;
     int o = 0;
     mp.sc = o;  o += 20;
+    mp.cw = o;  o += nmpc::CW_NCOEF;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
     mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / tri kernels)
@@ -961,6 +979,11 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : 64);
     if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments: force the two-point layout
         if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
+    }
+    h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
+                       pb->ndyn == nmpc::ShapeDefault::NDYN;
+    if (const char *env = getenv("NMPC_SHAPE")) {              // experiments: force the run-time-shape kernel
+        if (!strcmp(env, "any")) h->shape_default = false;
     }
     h->map = make_map(*pb, op.lbfgs_memory, h->P);
     h->d_queue = nullptr;
@@ -1039,7 +1062,8 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
-    if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel, dim3(grid), dim3(64), lds, s, a);
+    if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());

@@ -32,13 +32,14 @@ __device__ __forceinline__ double point_scalar(double v, int k)
 // FBE at the cached point; the gradient step x - gamma g is recomputed (bitwise the same value)
 #define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
 
+template <class SH>
 __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 {
     constexpr int P = 20, COLS = lay_cols<P>();
     extern __shared__ double lds[];
     lds_double *L = (lds_double *)lds;
     const int lane = threadIdx.x, h = lay_group<P>(lane), t = lay_stage<P>(lane);
-    const int N = a.pb.N, m = a.op.lbfgs_memory;
+    const int N = shape_N<SH>(a), m = a.op.lbfgs_memory;
     const bool in = t < N;
     const int f2off = a.map.f2 + h * (a.n2 + 1);
     // lane holding this stage in query point 0 / 1 / 2 (lanes beyond the horizon: themselves)
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 
         double vref;
         DynStage dyn;
-        prepare_instance<P>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+        prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
 
         // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
         const double *u0 = a.u + (size_t)inst * a.n_u;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 #ifdef NMPC_PROFILE
             NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
 #endif
-            eval_psi<P>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+            eval_psi<P, SH>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
