@@ -32,6 +32,22 @@ __device__ __forceinline__ double dpp_mov(double v)
     return __hiloint2double(hi, lo);
 }
 
+// same, but lanes of masked-off rows keep `old` (the destination register is tied to it)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_old(double old, double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// +0.0 in one instruction (as two 32-bit halves the compiler spends two v_mov_b32 on it)
+__device__ __forceinline__ double zero_pair()
+{
+    double z;
+    asm("v_mov_b64 %0, 0" : "=v"(z));
+    return z;
+}
+
 __device__ __forceinline__ double lane_get(double v, int src_lane)
 {
     // ds_bpermute_b32 x2: pull `v` from an arbitrary lane of the wave (slow path, rarely used)
@@ -177,8 +193,10 @@ __device__ __forceinline__ double group_sum<20>(double v, int lane)
         const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x114, 0x8, 0x8, false);
         v = __hiloint2double(hi, lo);
     }
-    v = v + dpp_mov<0x141, 0x7>(v);         // rows 0..2 only; row 3 adds 0.0
-    v = v + dpp_mov<0x140, 0x7>(v);
+    double o = dpp_mov_old<0x141, 0x7>(zero_pair(), v);     // rows 0..2 only; row 3 adds 0.0
+    v = v + o;
+    o = dpp_mov_old<0x140, 0x7>(o, v);                      // (row 3 of `o` is still 0.0)
+    v = v + o;
     const int q = lay_group<20>(lane);
     const int partner = lane < 48 ? 48 + 4 * q : 16 * q;
     return v + lane_get(v, partner);        // block 0 + block 1 (commutative: same bits on both sides)
@@ -192,8 +210,10 @@ __device__ __forceinline__ double group_prefix<20>(double v, int lane)
     v = v + ((tail && (lane & 3) < 1) ? 0.0 : o);
     o = dpp_mov<0x112>(v);
     v = v + ((tail && (lane & 3) < 2) ? 0.0 : o);
-    v = v + dpp_mov<0x114, 0x7>(v);
-    v = v + dpp_mov<0x118, 0x7>(v);
+    o = dpp_mov_old<0x114, 0x7>(zero_pair(), v);
+    v = v + o;
+    o = dpp_mov_old<0x118, 0x7>(o, v);
+    v = v + o;
     const int q = (lane - 48) >> 2;
     const double carry = lane_get(v, (tail && lane < 60) ? 16 * q + 15 : lane);     // last entry of block 0
     return v + (tail ? carry : 0.0);
@@ -207,8 +227,10 @@ __device__ __forceinline__ double group_suffix<20>(double v, int lane)
     v = v + ((tail && (lane & 3) > 2) ? 0.0 : o);
     o = dpp_mov<0x102>(v);
     v = v + ((tail && (lane & 3) > 1) ? 0.0 : o);
-    v = v + dpp_mov<0x104, 0x7>(v);
-    v = v + dpp_mov<0x108, 0x7>(v);
+    o = dpp_mov_old<0x104, 0x7>(zero_pair(), v);
+    v = v + o;
+    o = dpp_mov_old<0x108, 0x7>(o, v);
+    v = v + o;
     const double carry = lane_get(v, tail ? lane : 48 + 4 * (lane >> 4));            // first entry of block 1
     return v + (tail ? 0.0 : carry);
 }

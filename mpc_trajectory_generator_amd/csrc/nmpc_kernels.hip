@@ -184,7 +184,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
-    const bool in = t < N;
+    // every stage lane of the tri layout is inside a 20-stage horizon; lanes 60..63 then hold
+    // don't-care values that no cross-lane operation lets into the other lanes (nmpc_device.h)
+    constexpr bool FULL = P == 20 && SH::N == 20;
+    const bool in_r = t < N;                    // a real stage
+    const bool in = FULL ? true : in_r;         // arithmetic masks: compile-time true when FULL
 #ifdef NMPC_PROFILE
     extern __shared__ long long nmpc_prof_lds[];
     long long *nmpc_evt = nmpc_prof_lds + 4096 + (threadIdx.x == 0 ? 0 : 8);   // lane 0 accumulates; others to a dummy row
@@ -303,7 +307,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             for (int j = 0; j < 4; ++j) {
                 const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
                 const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
-                bits |= (in && h > 0.0 ? 1u : 0u) << j;
+                bits |= (in_r && h > 0.0 ? 1u : 0u) << j;
             }
             if (k < 32) m_lo |= bits << k; else m_hi |= bits << (k - 32);
         }
@@ -326,7 +330,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                     const double eb = fma(dx, sa, -(dy * ca));
                     const double h = fma(-(eb * eb), dv_[k][DY_IRY2], fma(-(ea * ea), dv_[k][DY_IRX2], 1.0));   // (:118)
                     dyh[k] = in ? fmax(h, 0.0) : 0.0;
-                    m_dy |= (dyh[k] > 0.0 ? 1u : 0u) << k;
+                    m_dy |= (in_r && dyh[k] > 0.0 ? 1u : 0u) << k;
                 }
             }
         }

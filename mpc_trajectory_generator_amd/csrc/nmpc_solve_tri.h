@@ -26,8 +26,8 @@ __device__ __forceinline__ double point_scalar(double v, int k)
 #define NMPC_HALF_STEP(xv, xw)                                                 \
     do {                                                                       \
         const double s1_ = fma(-gamma, gv, (xv)), s2_ = fma(-gamma, gw, (xw)); \
-        hv = in ? clampd(s1_, vmin, vmax) : s1_;                               \
-        hw = in ? clampd(s2_, -wmax, wmax) : s2_;                              \
+        hv = ina ? clampd(s1_, vmin, vmax) : s1_;                              \
+        hw = ina ? clampd(s2_, -wmax, wmax) : s2_;                             \
     } while (0)
 // FBE at the cached point; the gradient step x - gamma g is recomputed (bitwise the same value)
 #define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
@@ -41,6 +41,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
     const int lane = threadIdx.x, h = lay_group<P>(lane), t = lay_stage<P>(lane);
     const int N = shape_N<SH>(a), m = a.op.lbfgs_memory;
     const bool in = t < N;
+    // arithmetic masks: with a 20-stage horizon every stage lane is inside it, and lanes 60..63 may hold
+    // don't-care vector values (no cross-lane operation lets them into other lanes; their scalars are group 2's)
+    constexpr bool FULL = SH::N == P;
+    const bool ina = FULL ? true : in;
     const int f2off = a.map.f2 + h * (a.n2 + 1);
     // lane holding this stage in query point 0 / 1 / 2 (lanes beyond the horizon: themselves)
     const int src0 = in ? lay_lane<P>(0, t) : lane, src1 = in ? lay_lane<P>(1, t) : lane, src2 = in ? lay_lane<P>(2, t) : lane;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 #pragma unroll
                         for (int k = 0; k < MAXMEM; ++k) {
                             int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
-                            const dbl2 s_ = ld_pair(LS, slot * N + tt, in), y_ = ld_pair(LY, slot * N + tt, in);
+                            const dbl2 s_ = ld_pair(LS, slot * N + tt, ina), y_ = ld_pair(LY, slot * N + tt, ina);
                             const double al = Lrho[slot] * hdot<P>(s_.x, s_.y, dv, dw, lane);
                             alpha[k] = al;
                             dv = fma(-al, y_.x, dv); dw = fma(-al, y_.y, dw);
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 #pragma unroll
                         for (int k = MAXMEM - 1; k >= 0; --k) {
                             int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
-                            const dbl2 s_ = ld_pair(LS, slot * N + tt, in), y_ = ld_pair(LY, slot * N + tt, in);
+                            const dbl2 s_ = ld_pair(LS, slot * N + tt, ina), y_ = ld_pair(LY, slot * N + tt, ina);
                             const double be = Lrho[slot] * hdot<P>(y_.x, y_.y, dv, dw, lane);
                             const double ab = alpha[k] - be;
                             dv = fma(ab, s_.x, dv); dw = fma(ab, s_.y, dw);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                         double alpha[MAXMEM];
                                                 const int tt = in ? t : 0;               // lanes beyond the horizon read lane 0's pair and drop it
                         int slot = n_head;
-                        dbl2 sc_ = ld_pair(LS, slot * N + tt, in), yc_ = ld_pair(LY, slot * N + tt, in);
+                        dbl2 sc_ = ld_pair(LS, slot * N + tt, ina), yc_ = ld_pair(LY, slot * N + tt, ina);
                         double rc_ = Lrho[slot];
 #pragma unroll
                         for (int k = 0; k < MAXMEM; ++k) {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                                 double rn_ = 0.0;
                                 if (k + 1 < n_active) {
                                     slot = slot + 1 == m ? 0 : slot + 1;
-                                    sn_ = ld_pair(LS, slot * N + tt, in); yn_ = ld_pair(LY, slot * N + tt, in); rn_ = Lrho[slot];
+                                    sn_ = ld_pair(LS, slot * N + tt, ina); yn_ = ld_pair(LY, slot * N + tt, ina); rn_ = Lrho[slot];
                                 }
                                 const double al = rc_ * hdot<P>(sc_.x, sc_.y, dv, dw, lane);
                                 alpha[k] = al;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                                 double rn_ = 0.0;
                                 if (k > 0) {
                                     slot = slot == 0 ? m - 1 : slot - 1;
-                                    sn_ = ld_pair(LS, slot * N + tt, in); yn_ = ld_pair(LY, slot * N + tt, in); rn_ = Lrho[slot];
+                                    sn_ = ld_pair(LS, slot * N + tt, ina); yn_ = ld_pair(LY, slot * N + tt, ina); rn_ = Lrho[slot];
                                 }
                                 const double be = rc_ * hdot<P>(yc_.x, yc_.y, dv, dw, lane);
                                 const double ab = alpha[k] - be;
@@ -272,9 +276,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 // init evaluates u (points 0, 2) and u + h (point 1), h_i = max(1e-6 u_i, 1e-12)
                 const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
                 const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
-                norm_h = sqrt(group_sum<P>(in ? fma(h1, h1, h2 * h2) : 0.0, lane));
-                zv = h == 1 ? (in ? uv + h1 : 0.0) : uv;
-                zw = h == 1 ? (in ? uw + h2 : 0.0) : uw;
+                norm_h = sqrt(group_sum<P>(ina ? fma(h1, h1, h2 * h2) : 0.0, lane));
+                zv = h == 1 ? (ina ? uv + h1 : 0.0) : uv;
+                zw = h == 1 ? (ina ? uw + h2 : 0.0) : uw;
                 need_grad = true; state = D_INIT;
             }
             if (!running) break;
@@ -374,11 +378,11 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
-                const double ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
-                const double ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+                const double ypv = ina ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
+                const double ypw = ina ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
                 *Lyp = dbl2{ypv, ypw};
                 const double d1 = ypv - yv, d2 = ypw - yw;
-                dy_norm_plus = sqrt(group_sum<P>(in ? fma(d1, d1, d2 * d2) : 0.0, lane));
+                dy_norm_plus = sqrt(group_sum<P>(ina ? fma(d1, d1, d2 * d2) : 0.0, lane));
                 f2_norm_plus = sqrt(pen);
                 const double SMALL = DBL_EPSILON;
                 const bool crit1 = nu > 0 && __any(dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
