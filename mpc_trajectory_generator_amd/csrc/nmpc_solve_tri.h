@@ -298,10 +298,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 #ifdef NMPC_PROFILE
             NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
 #endif
+#ifdef NMPC_MARKS
+            asm volatile("; MARK 10");
+#endif
             eval_psi<P, SH>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
+#endif
+#ifdef NMPC_MARKS
+            asm volatile("; MARK 11");
 #endif
             const double psiA = point_scalar(psi, 0), psiB = point_scalar(psi, 1), psiC = point_scalar(psi, 2);
             // one trial of the current direction: psi, grad psi were evaluated by query point K at step tau

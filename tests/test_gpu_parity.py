@@ -94,6 +94,51 @@ def test_solve_nobs50_and_dynamic_obstacles(solvers):
     assert_same_solution(solvers("cfg4").solve(P), oracle_for(cfg).solve_batch(P, threads=8))
 
 
+SHAPES = [(20, 10, 2), (20, 0, 0), (19, 10, 3), (17, 4, 1), (16, 0, 0), (15, 3, 2), (5, 1, 3), (2, 0, 0),
+          (21, 10, 3), (32, 64, 3), (33, 10, 3), (64, 3, 0)]
+
+
+@pytest.mark.parametrize("N,nobs,ndyn", SHAPES)
+def test_shape_sweep_bit_exact(N, nobs, ndyn):
+    """Every lane layout (three / two / one query point per wave) with full and partial horizons,
+    padded and empty obstacle tables: cost layer and solve against the oracle, bit for bit."""
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = load_config(N_hor=N, Nobs=nobs, Ndynobs=ndyn)
+    P = synthetic_batch(cfg, 11, 10, 100 * N + nobs, random_dyn=ndyn > 0)
+    s, o = BatchSolver(cfg, max_batch=16), oracle_for(cfg)
+    try:
+        gpu = s.solve(P)
+        assert_same_solution(gpu, o.solve_batch(P, threads=8))
+        rng = np.random.default_rng(N)
+        U = gpu[0] + rng.normal(0, 0.05, gpu[0].shape)
+        c = rng.choice([0.0, 1.0, 125.0], size=len(P))
+        Y = rng.normal(0, 1.0, (len(P), cfg.n1))
+        psi, g, F1, F2 = s.evaluate(P, U, c, Y)
+        for i in range(len(P)):
+            po, go, F1o, F2o = o.eval(P[i], U[i], c[i], Y[i])
+            assert psi[i] == po and np.array_equal(g[i], go)
+            assert np.array_equal(F1[i], F1o) and np.array_equal(F2[i], F2o)
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("env", [{"NMPC_LAYOUT": "dual"}, {"NMPC_SHAPE": "any"}])
+def test_alternative_kernels_same_bits(monkeypatch, env):
+    """The default.yaml shape has a shape-specialised three-point kernel; the run-time-shape kernel and
+    the two-point kernel (used for 20 < N_hor <= 32) must give the same bits on it."""
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = named_config("cfg1")
+    P = synthetic_batch(cfg, 11, 48, 4242)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = BatchSolver(cfg, max_batch=64)
+    try:
+        assert_same_solution(s.solve(P), oracle_for(cfg).solve_batch(P, threads=8))
+    finally:
+        s.close()
+
+
 def test_solve_warm_start_multipliers_penalty(solvers):
     cfg = named_config("cfg1")
     s, o = solvers("cfg1"), oracle_for(cfg)
