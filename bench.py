@@ -175,7 +175,7 @@ def main():
         "max_inner_iters": int(st["num_inner_iterations"].max()),
         "roofline": {"bound": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
-                     "traffic": None, "kernel": "nmpc_solve_kernel", "kernel_ms": kern_ms,
+                     "traffic": None, "kernel": solver.kernel_name, "kernel_ms": kern_ms,
                      "flops_per_launch": flops,
                      "note": "f64 vector-ALU issue bounds this kernel, not HBM or MFMA (SURVEY.md section 8d); "
                              "MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},

@@ -118,6 +118,8 @@ void nmpc_free(nmpc_handle *h);
 int nmpc_ping(const nmpc_handle *h);
 const char *nmpc_last_error(const nmpc_handle *h);
 int nmpc_abi_version(void);
+/* Diagnostic: the solve kernel this handle launches (the name a rocprofv3 kernel trace shows). */
+const char *nmpc_kernel_name(const nmpc_handle *h);
 
 /* Device path: every pointer is device memory on the handle's device; the launch is enqueued on
  * `stream` (a hipStream_t, NULL = default stream) and the call returns without synchronising.

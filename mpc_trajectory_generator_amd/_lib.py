@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_CSRC, "libnmpc_hip.so")
 # every symbol include/nmpc_solver.h declares
 SYMBOLS = (
     "nmpc_default_opts", "nmpc_n_u", "nmpc_n_p", "nmpc_n1", "nmpc_n2", "nmpc_new", "nmpc_free",
-    "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_solve_batch_device",
+    "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_kernel_name", "nmpc_solve_batch_device",
     "nmpc_solve_batch_host", "nmpc_eval_batch_device", "nmpc_eval_batch_host",
     "nmpc_test_sincos_host", "nmpc_test_divsqrt_host",
 )
@@ -87,6 +87,8 @@ def load_library() -> C.CDLL:
     lib.nmpc_ping.argtypes = [vp]
     lib.nmpc_last_error.argtypes = [vp]
     lib.nmpc_last_error.restype = C.c_char_p
+    lib.nmpc_kernel_name.argtypes = [vp]
+    lib.nmpc_kernel_name.restype = C.c_char_p
     lib.nmpc_abi_version.restype = C.c_int
     lib.nmpc_solve_batch_device.argtypes = [vp, C.c_int] + [vp] * 7
     lib.nmpc_solve_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, vp]

@@ -1030,6 +1030,12 @@ void nmpc_free(nmpc_handle *h)
 
 int nmpc_ping(const nmpc_handle *h) { return (h && h->alive) ? NMPC_OK : NMPC_ERR_DEAD_HANDLE; }
 const char *nmpc_last_error(const nmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
+const char *nmpc_kernel_name(const nmpc_handle *h)
+{
+    if (!h) return "";
+    if (h->P == 20) return h->shape_default ? "nmpc_solve_tri_kernel<ShapeDefault>" : "nmpc_solve_tri_kernel<ShapeAny>";
+    return h->P == 32 ? "nmpc_solve_dual_kernel" : "nmpc_solve_kernel<64>";
+}
 
 static void fill_args(const nmpc_handle *h, KArgs &a, int B)
 {

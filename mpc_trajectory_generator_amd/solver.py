@@ -65,6 +65,11 @@ class BatchSolver:
         except Exception:
             pass
 
+    @property
+    def kernel_name(self) -> str:
+        """Name of the solve kernel this handle launches (diagnostic; what a kernel trace shows)."""
+        return self.lib.nmpc_kernel_name(self._h).decode()
+
     def ping(self):
         self._check(self.lib.nmpc_ping(self._h))
 

@@ -1,13 +1,16 @@
+"""Per-section cycle counts of single instances (library built with -DNMPC_PROFILE).
+The status fields are overloaded with s_memtime deltas by that build."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
 from mpc_trajectory_generator_amd import named_config
 from mpc_trajectory_generator_amd.solver import BatchSolver
 from mpc_trajectory_generator_amd.harness import synthetic_batch
+from mpc_trajectory_generator_amd.frontend import random_routes
 cfg = named_config("cfg1")
 sol = BatchSolver(cfg, max_batch=8192)
-P = synthetic_batch(cfg, 11, 1024, 0)
-for b in (460, 337, 423, 814):
+P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=1000))
+for b in (170, 4175, 0, 1):
     sol.solve(P[b:b + 1])
     _, _, s = sol.solve(P[b:b + 1])
     n = s["reserved"][0]
