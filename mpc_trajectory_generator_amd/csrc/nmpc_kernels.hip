@@ -39,11 +39,12 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
+    int par;     // 12 parked solver scalars (tri kernel)
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x P per-stage ellipse data
-    int vec;     // 4 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+
+    int vec;     // 6 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed
     int rho;     // m
     int S, Y;    // m slots x N lanes x (v, w)
     int total;
@@ -950,6 +951,7 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     int o = 0;
     mp.sc = o;  o += 20;
     mp.cw = o;  o += nmpc::CW_NCOEF;
+    mp.par = o; o += 12;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
     mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / tri kernels)
@@ -957,7 +959,7 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     const int cols = P == 20 ? 24 : P;                // nmpc::lay_cols
     mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * cols;
     o = (o + 1) & ~1;
-    mp.vec = o; o += 4 * 2 * cols;
+    mp.vec = o; o += 6 * 2 * cols;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
     mp.S = o;   o += 2 * pb.N * m;
     mp.Y = o;   o += 2 * pb.N * m;

@@ -53,8 +53,23 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
     lds_double *Lrho = L + a.map.rho;
     lds_double2 *Los = (lds_double2 *)(L + a.map.vec) + t;      // parked pairs, one column per stage
     lds_double2 *Log = Los + COLS, *Lq = Los + 2 * COLS, *Lyp = Los + 3 * COLS;
+    lds_double2 *Ly = Los + 4 * COLS;                           // multipliers y (read by every evaluation)
+    lds_double *Lvr = L + a.map.vec + 2 * 5 * COLS + t;         // reference speed of this stage
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
+    lds_double *Lpar = L + a.map.par;
+#define pk_eps_nu Lpar[0]
+#define pk_dy_norm Lpar[1]
+#define pk_f2_norm Lpar[2]
+#define pk_dy_norm_plus Lpar[3]
+#define pk_f2_norm_plus Lpar[4]
+#define pk_last_fpr Lpar[5]
+#define pk_last_cost Lpar[6]
+#define pk_norm_h Lpar[7]
+#define pk_Lc Lpar[8]
+#define pk_H0 Lpar[9]
+#define pk_sigma Lpar[10]
+#define pk_c_lip Lpar[11]
 
     for (;;) {
         // ------------------------------------------------------------------ next instance from the queue
@@ -64,22 +79,27 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
         if (nxt >= (unsigned)a.B) break;
         const int inst = a.order ? a.order[nxt] : (int)nxt;
 
-        double vref;
+        double vref_;
         DynStage dyn;
-        prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+        prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref_, dyn);
+        *Lvr = vref_;
 
         // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
         const double *u0 = a.u + (size_t)inst * a.n_u;
         double uv = in ? u0[2 * t] : 0.0, uw = in ? u0[2 * t + 1] : 0.0;
-        double yv = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + t] : 0.0;
-        double yw = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + N + t] : 0.0;
-        *Lyp = dbl2{yv, yw};
+        {
+            const double yv0 = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + t] : 0.0;
+            const double yw0 = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + N + t] : 0.0;
+            *Lyp = dbl2{yv0, yw0};
+            *Ly = dbl2{yv0, yw0};
+        }
         *Lq = dbl2{0.0, 0.0};                    // gradient_u_previous (AKKT residual) starts at zero
         double gv = 0, gw = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
         double pv = 0, pw = 0;                    // line-search trial point of THIS half
         double zv = 0, zw = 0;                    // query point of THIS half
         bool need_grad = true;
-        double cost = 0, Lc = 0, gamma = 0, sigma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0, norm_h = 0, H0 = 1;
+        double cost = 0, gamma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0;
+        pk_Lc = 0.0; pk_sigma = 0.0; pk_H0 = 1.0;
         double fbe_u = 0;                         // FBE at the current iterate, valid while fbe_ok (an accepted
         bool fbe_ok = false;                      // trial's FBE is the next iteration's: same operands, same bits)
         int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
@@ -92,9 +112,11 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
         const double c0 = a.c0 ? a.c0[inst] : 0.0;
         double pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
         double cbar_inv = 1.0 / fmax(pen_c, 1.0);          // 1 / max(c, 1), refreshed when c changes
-        double c_lip = 0;                                   // 0.95 / (2 gamma), refreshed when gamma changes
-        double eps_nu = a.op.initial_tolerance;
-        double dy_norm = 0, f2_norm = 0, dy_norm_plus = DBL_MAX, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
+        pk_c_lip = 0.0;                                     // 0.95 / (2 gamma), refreshed when gamma changes
+        // scalars touched once per inner solve / outer iteration are parked in LDS (every lane writes the
+        // same value) instead of occupying a VGPR pair each for the whole solve
+        pk_eps_nu = a.op.initial_tolerance;
+        pk_dy_norm = 0.0; pk_f2_norm = 0.0; pk_dy_norm_plus = DBL_MAX; pk_f2_norm_plus = 0.0; pk_last_fpr = 0.0; pk_last_cost = 0.0; pk_norm_h = 0.0;
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
 
@@ -114,9 +136,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 f_back = false;
                 lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
                 fbe_ok = false;
-                Lc *= 2.0; gamma /= 2.0;
-                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-                c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                pk_Lc *= 2.0; gamma /= 2.0;
+                pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
                 nr2 = hdot<P>(rv, rw, rv, rw, lane);
@@ -151,7 +173,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test
                     const dbl2 q_ = *Lq;
                     const double a1 = rv / gamma + (gv - q_.x), a2 = rw / gamma + (gw - q_.y);
-                    exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu);
+                    exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < pk_eps_nu);
                 }
                 if (exit_now) {
                     f_done = true;
@@ -162,7 +184,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 } else {
                     lip_it = 0;
                     // ---- tentative L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
-                    n_first = lb_first; n_head = lb_head; n_active = lb_active; n_H0 = H0; n_take_old = false;
+                    n_first = lb_first; n_head = lb_head; n_active = lb_active; n_H0 = pk_H0; n_take_old = false;
                     if (lb_first) {
                         n_first = false; n_take_old = true;
                     } else {
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                         }
                     }
                     if (!fbe_ok) { fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
-                    rhs_ls = fbe_u - sigma * nr2;
+                    rhs_ls = fbe_u - pk_sigma * nr2;
                     tau = 1.0; ls_n = 0;
                     const double th_ = h == 2 ? 0.5 : 1.0;
                     const double omt = 1.0 - th_;
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 f_done = false;
                 inner_status = num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
                 inner_total += num_iter;
-                last_fpr = norm_r; last_cost = cost;
+                pk_last_fpr = norm_r; pk_last_cost = cost;
                 uv = hv; uw = hw;                                        // PANOC returns the feasible half step
                 const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
                 if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
@@ -271,12 +293,12 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
             // ---------------------------------------------------------------- start an inner solve
             if (f_start) {
                 f_start = false;
-                yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);      // y <- Pi_Y(y)
+                { const dbl2 y_ = *Ly; *Ly = dbl2{clampd(y_.x, -1e12, 1e12), clampd(y_.y, -1e12, 1e12)}; }      // y <- Pi_Y(y)
                 lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
                 // init evaluates u (points 0, 2) and u + h (point 1), h_i = max(1e-6 u_i, 1e-12)
                 const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
                 const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
-                norm_h = sqrt(group_sum<P>(ina ? fma(h1, h1, h2 * h2) : 0.0, lane));
+                pk_norm_h = sqrt(group_sum<P>(ina ? fma(h1, h1, h2 * h2) : 0.0, lane));
                 zv = h == 1 ? (ina ? uv + h1 : 0.0) : uv;
                 zw = h == 1 ? (ina ? uw + h2 : 0.0) : uw;
                 need_grad = true; state = D_INIT;
@@ -301,7 +323,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
 #ifdef NMPC_MARKS
             asm volatile("; MARK 10");
 #endif
-            eval_psi<P, SH>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+            const dbl2 ycur = *Ly;
+            const double yv = ycur.x, yw = ycur.y;
+            eval_psi<P, SH>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
@@ -332,10 +356,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 n_grad += 2;
                 cost = psiA; gv = point_get(egv, src0); gw = point_get(egw, src0);
                 const double d1 = point_get(egv, src1) - gv, d2 = point_get(egw, src1) - gw;
-                Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / norm_h;
-                gamma = GAMMA_L_COEFF / fmax(Lc, MIN_LIPSCHITZ_CONSTANT);
-                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-                c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                pk_Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / pk_norm_h;
+                gamma = GAMMA_L_COEFF / fmax(pk_Lc, MIN_LIPSCHITZ_CONSTANT);
+                pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
                 fbe_ok = false;
                 f_begin = true;
@@ -345,8 +369,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 // speculative trial u+(tau = 1) on the tentative direction.
                 n_cost++;
                 const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
-                                 + c_lip * nr2;
-                if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
+                                 + pk_c_lip * nr2;
+                if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(pk_Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
                     f_back = true;                                       // (speculation discarded)
                 } else {
                     if (state == D_LIP) {
@@ -361,12 +385,12 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                             f_end = true;
                         } else {
                             dv = rv; dw = rw;                            // empty buffer: d = r
-                            rhs_ls = NMPC_FBE(uv, uw) - sigma * nr2;
+                            rhs_ls = NMPC_FBE(uv, uw) - pk_sigma * nr2;
                             tau = 1.0; ls_n = 0;
                             f_trials = true;
                         }
                     } else {
-                        lb_first = n_first; lb_head = n_head; lb_active = n_active; H0 = n_H0;      // commit
+                        lb_first = n_first; lb_head = n_head; lb_active = n_active; pk_H0 = n_H0;      // commit
                         if (n_take_old) { *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw}; }
                         NMPC_TAKE_TRIAL(psiB, src1);                     // tau = 1
                         if (rejected) NMPC_TAKE_TRIAL(psiC, src2);       // tau = 1/2
@@ -388,21 +412,21 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
                 const double ypw = ina ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
                 *Lyp = dbl2{ypv, ypw};
                 const double d1 = ypv - yv, d2 = ypw - yw;
-                dy_norm_plus = sqrt(group_sum<P>(ina ? fma(d1, d1, d2 * d2) : 0.0, lane));
-                f2_norm_plus = sqrt(pen);
+                pk_dy_norm_plus = sqrt(group_sum<P>(ina ? fma(d1, d1, d2 * d2) : 0.0, lane));
+                pk_f2_norm_plus = sqrt(pen);
                 const double SMALL = DBL_EPSILON;
-                const bool crit1 = nu > 0 && __any(dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
-                const bool crit2 = a.n2 == 0 || __any(f2_norm_plus <= a.op.delta_tolerance + SMALL);
-                const bool crit3 = __any(eps_nu <= a.op.tolerance + SMALL);
+                const bool crit1 = nu > 0 && __any(pk_dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
+                const bool crit2 = a.n2 == 0 || __any(pk_f2_norm_plus <= a.op.delta_tolerance + SMALL);
+                const bool crit3 = __any(pk_eps_nu <= a.op.tolerance + SMALL);
                 if (crit1 && crit2 && crit3) {
                     final_status = inner_status; running = false;
                 } else {
-                    const bool stall = nu == 0 || __any(dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
-                                                        f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
+                    const bool stall = nu == 0 || __any(pk_dy_norm_plus <= a.op.sufficient_decrease * pk_dy_norm + SMALL &&
+                                                        pk_f2_norm_plus <= a.op.sufficient_decrease * pk_f2_norm + SMALL);
                     if (!stall) { pen_c *= a.op.penalty_update; cbar_inv = 1.0 / fmax(pen_c, 1.0); }
-                    eps_nu = fmax(a.op.tolerance_update * eps_nu, a.op.tolerance);
-                    yv = ypv; yw = ypw;
-                    dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
+                    pk_eps_nu = fmax(a.op.tolerance_update * pk_eps_nu, a.op.tolerance);
+                    *Ly = dbl2{ypv, ypw};
+                    pk_dy_norm = pk_dy_norm_plus; pk_f2_norm = pk_f2_norm_plus;
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
                     else f_start = true;
@@ -428,11 +452,11 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
             s.num_cost_evals = n_cost;
             s.num_grad_evals = n_grad;
             s.reserved = n_pass;                 // evaluation passes actually executed (diagnostic)
-            s.last_problem_norm_fpr = last_fpr;
-            s.delta_y_norm_over_c = dy_norm_plus / pen_c;
-            s.f2_norm = f2_norm_plus;
+            s.last_problem_norm_fpr = pk_last_fpr;
+            s.delta_y_norm_over_c = pk_dy_norm_plus / pen_c;
+            s.f2_norm = pk_f2_norm_plus;
             s.penalty = pen_c;
-            s.cost = last_cost;
+            s.cost = pk_last_cost;
             s.solve_time_ms = 0.0;
 #ifdef NMPC_PROFILE
             {
@@ -450,6 +474,18 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_tri_kernel(KArgs a)
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
     }
 }
+#undef pk_eps_nu
+#undef pk_dy_norm
+#undef pk_f2_norm
+#undef pk_dy_norm_plus
+#undef pk_f2_norm_plus
+#undef pk_last_fpr
+#undef pk_last_cost
+#undef pk_norm_h
+#undef pk_Lc
+#undef pk_H0
+#undef pk_sigma
+#undef pk_c_lip
 #undef NMPC_TAKE_TRIAL
 #undef NMPC_HALF_STEP
 #undef NMPC_FBE
