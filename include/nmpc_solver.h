@@ -144,6 +144,47 @@ int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const doubl
 int nmpc_eval_batch_host(nmpc_handle *h, int B, const double *p, const double *u, const double *c,
                          const double *y, double *psi, double *grad, double *F1, double *F2);
 
+/* ---- the receding-horizon loop on device ------------------------------------------------------
+ * B robots follow one route in lock step; one step = assemble p (the body of the reference's
+ * PathGenerator.run loop, src/path_generator.py:290-382), solve the batch warm-started from the
+ * previous controls and multipliers (mng.call, src/mpc/mpc_generator.py:206), advance the states
+ * over num_steps_taken controls (src/mpc/mpc_generator.py:223-235) and evaluate the terminal test
+ * (src/path_generator.py:397).  Nothing crosses PCIe between steps. */
+typedef struct nmpc_route {
+    int32_t n_ref;             /* samples of rough_ref                       src/mpc/mpc_generator.py:17-57  */
+    int32_t n_vert;            /* vertices the route bends around            src/visibility/visibility.py:126-139 */
+    int32_t n_brake;           /* entries of the braking tables (>= 1)       src/path_generator.py:439-477   */
+    int32_t num_steps_taken;   /* controls applied per solve                 configs/default.yaml:16         */
+    const double *x_ref, *y_ref, *theta_ref;    /* [n_ref]   host memory, copied by nmpc_loop_new */
+    const double *vert_xy;                      /* [n_vert][2]                                       */
+    const double *brake_vel, *brake_dist;       /* [n_brake]                                         */
+    double end[3];             /* goal pose                                  src/path_generator.py:327      */
+    double base_speed;         /* lin_vel_max * throttle_ratio               src/path_generator.py:284      */
+    double radius;             /* static circle radius                       src/path_generator.py:300-301  */
+    double dyn_pad;            /* added to the ellipse radii                 src/visibility/visibility.py:208-209 */
+    double weights[10];        /* p[10:20]                                   src/path_generator.py:226-227  */
+} nmpc_route;
+
+typedef struct nmpc_loop nmpc_loop;
+
+/* starts [B][3] (x, y, theta); idx0 [B] = reference sample each robot starts at, or NULL (0, as
+ * the reference).  K <= Ndynobs moving ellipses per robot, dyn [B][K][8] = (p1x, p1y, p2x, p2y,
+ * freq, rx, ry, angle) of the reference's linear law (visibility.py:156-166), or NULL with K = 0.
+ * max_steps > 0 also records the trajectory on device. */
+int nmpc_loop_new(nmpc_handle *h, const nmpc_route *route, int B, const double *starts,
+                  const int32_t *idx0, int K, const double *dyn, int max_steps, nmpc_loop **out);
+void nmpc_loop_free(nmpc_loop *l);
+/* Enqueues assemble -> solve -> advance on `stream`; does not synchronise. */
+int nmpc_loop_step(nmpc_loop *l, void *stream);
+/* Synchronises, then copies what is asked for (NULL = skip) to host memory:
+ * state [B][3], last_u [B][2], idx [B], done [B], status [B] of the last solve. */
+int nmpc_loop_read(nmpc_loop *l, double *state, double *last_u, int32_t *idx, uint8_t *done,
+                   nmpc_status *status);
+/* The parameter vectors of the last step p [B][n_p], the controls u [B][n_u] and multipliers y [B][n1]. */
+int nmpc_loop_params(nmpc_loop *l, double *p, double *u, double *y);
+/* Recorded trajectory: rows [steps * num_steps_taken + 1][B][3]; returns the row count (or < 0). */
+int nmpc_loop_trajectory(nmpc_loop *l, double *rows, int max_rows);
+
 /* Arithmetic primitives of the kernels, exported for bit-level checks: out_s/out_c [n]. */
 int nmpc_test_sincos_host(nmpc_handle *h, int n, const double *x, double *out_s, double *out_c);
 /* a/b and sqrt(a) as the device computes them: out_div/out_sqrt [n]. */

@@ -20,6 +20,8 @@ SYMBOLS = (
     "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_kernel_name", "nmpc_solve_batch_device",
     "nmpc_solve_batch_host", "nmpc_eval_batch_device", "nmpc_eval_batch_host",
     "nmpc_test_sincos_host", "nmpc_test_divsqrt_host",
+    "nmpc_loop_new", "nmpc_loop_free", "nmpc_loop_step", "nmpc_loop_read", "nmpc_loop_params",
+    "nmpc_loop_trajectory",
 )
 
 ERRORS = {0: "ok", -1: "bad problem", -2: "bad opts", -3: "bad argument", -4: "no HIP device",
@@ -43,6 +45,15 @@ class NmpcOpts(C.Structure):
                 ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("reserved", C.c_int32)]
 
 
+class NmpcRoute(C.Structure):
+    _dp = C.POINTER(C.c_double)
+    _fields_ = [("n_ref", C.c_int32), ("n_vert", C.c_int32), ("n_brake", C.c_int32), ("num_steps_taken", C.c_int32),
+                ("x_ref", _dp), ("y_ref", _dp), ("theta_ref", _dp), ("vert_xy", _dp),
+                ("brake_vel", _dp), ("brake_dist", _dp),
+                ("end", C.c_double * 3), ("base_speed", C.c_double), ("radius", C.c_double),
+                ("dyn_pad", C.c_double), ("weights", C.c_double * 10)]
+
+
 STATUS_DTYPE = np.dtype([("exit_status", "<i4"), ("num_outer_iterations", "<u4"),
                          ("num_inner_iterations", "<u4"), ("num_cost_evals", "<u4"),
                          ("num_grad_evals", "<u4"), ("reserved", "<u4"),
@@ -54,7 +65,7 @@ assert STATUS_DTYPE.itemsize == 72
 
 def build_library(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 the kernels in-tree (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("nmpc_kernels.hip", "nmpc_device.h", "nmpc_solve_dual.h", "Makefile")]
+    srcs = [os.path.join(_CSRC, f) for f in ("nmpc_kernels.hip", "nmpc_device.h", "nmpc_solve_dual.h", "nmpc_solve_tri.h", "nmpc_loop.h", "Makefile")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "nmpc_solver.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -96,6 +107,14 @@ def load_library() -> C.CDLL:
     lib.nmpc_eval_batch_host.argtypes = [vp, C.c_int] + [dp] * 8
     lib.nmpc_test_sincos_host.argtypes = [vp, C.c_int, dp, dp, dp]
     lib.nmpc_test_divsqrt_host.argtypes = [vp, C.c_int, dp, dp, dp, dp]
+    lib.nmpc_loop_new.argtypes = [vp, C.POINTER(NmpcRoute), C.c_int, dp, C.POINTER(C.c_int32), C.c_int, dp, C.c_int,
+                                  C.POINTER(vp)]
+    lib.nmpc_loop_free.argtypes = [vp]
+    lib.nmpc_loop_free.restype = None
+    lib.nmpc_loop_step.argtypes = [vp, vp]
+    lib.nmpc_loop_read.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), vp]
+    lib.nmpc_loop_params.argtypes = [vp, dp, dp, dp]
+    lib.nmpc_loop_trajectory.argtypes = [vp, dp, C.c_int]
     _lib = lib
     return lib
 

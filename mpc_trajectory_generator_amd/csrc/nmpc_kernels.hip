@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace nmpc {
 
@@ -808,6 +809,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 
 #include "nmpc_solve_dual.h"
 #include "nmpc_solve_tri.h"
+#include "nmpc_loop.h"
 
 // ---------------------------------------------------------------------------------------------
 // launch-order heuristic.  Iteration counts are heavy-tailed and a batch ends when its slowest
@@ -1190,6 +1192,170 @@ int nmpc_eval_batch_host(nmpc_handle *h, int B, const double *p, const double *u
     if (F1) HIP_TRY(h, hipMemcpy(F1, h->d_F1, B * n1 * 8, hipMemcpyDeviceToHost));
     if (F2 && n2) HIP_TRY(h, hipMemcpy(F2, h->d_F2, B * n2 * 8, hipMemcpyDeviceToHost));
     return NMPC_OK;
+}
+
+// ---- receding-horizon loop on device (nmpc_loop.h) ----
+struct nmpc_loop {
+    nmpc_handle *h;
+    nmpc::LoopArgs a;            // device pointers and constants; t / dyn_in / dyn_out / traj_row change per step
+    int steps, max_steps;
+    double *d_tab;               // route tables, one allocation
+    double *d_dynpar, *d_state, *d_last_u, *d_dyn[2], *d_P, *d_U, *d_Y, *d_traj;
+    int *d_idx;
+    unsigned char *d_done;
+    nmpc_status *d_st;
+};
+
+int nmpc_loop_new(nmpc_handle *h, const nmpc_route *r, int B, const double *starts, const int32_t *idx0, int K,
+                  const double *dyn, int max_steps, nmpc_loop **out)
+{
+    if (!h || !r || !out || !starts) return NMPC_ERR_BAD_ARG;
+    if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
+    if (B < 1 || B > h->max_batch || K < 0 || K > h->pb.ndyn || (K > 0 && !dyn) || max_steps < 0)
+        return fail(h, NMPC_ERR_BAD_ARG, "bad loop arguments");
+    if (idx0) for (int b = 0; b < B; ++b) if (idx0[b] < 0 || idx0[b] >= r->n_ref) return fail(h, NMPC_ERR_BAD_ARG, "idx0 out of range");
+    if (r->n_ref < 1 || r->n_vert < 0 || r->n_brake < 1 || r->num_steps_taken < 1 || r->num_steps_taken > h->pb.N ||
+        !r->x_ref || !r->y_ref || !r->theta_ref || !r->brake_vel || !r->brake_dist || (r->n_vert > 0 && !r->vert_xy))
+        return fail(h, NMPC_ERR_BAD_ARG, "bad route");
+    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc_loop *l = new nmpc_loop();
+    std::memset(l, 0, sizeof(*l));
+    l->h = h;
+    l->max_steps = max_steps;
+    nmpc::LoopArgs &a = l->a;
+    a.B = B; a.N = h->pb.N; a.nobs = h->pb.nobs; a.ndyn = h->pb.ndyn; a.K = K;
+    a.n_p = nmpc_n_p(&h->pb); a.n_u = nmpc_n_u(&h->pb);
+    a.n_ref = r->n_ref; a.n_vert = r->n_vert; a.n_brake = r->n_brake; a.s = r->num_steps_taken; a.t = 0;
+    a.ts = h->pb.ts; a.base = r->base_speed; a.radius = r->radius; a.pad = r->dyn_pad;
+    for (int i = 0; i < 3; ++i) a.end[i] = r->end[i];
+    for (int i = 0; i < 10; ++i) a.w[i] = r->weights[i];
+    const size_t n1 = nmpc_n1(&h->pb), ntab = 3 * (size_t)r->n_ref + 2 * (size_t)r->n_vert + 2 * (size_t)r->n_brake;
+    const size_t ndynrow = (size_t)a.ndyn * a.N * 5;
+    hipError_t e = hipMalloc((void **)&l->d_tab, (ntab ? ntab : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_dynpar, ((size_t)B * (K ? K : 1)) * 8 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_state, (size_t)B * 3 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_last_u, (size_t)B * 2 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_dyn[0], (size_t)B * (ndynrow ? ndynrow : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_dyn[1], (size_t)B * (ndynrow ? ndynrow : 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_P, (size_t)B * a.n_p * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_U, (size_t)B * a.n_u * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_Y, (size_t)B * n1 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_idx, (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_done, (size_t)B);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_st, (size_t)B * sizeof(nmpc_status));
+    if (e == hipSuccess && max_steps > 0)
+        e = hipMalloc((void **)&l->d_traj, ((size_t)max_steps * a.s + 1) * B * 3 * 8);
+    if (e != hipSuccess) { nmpc_loop_free(l); return fail(h, NMPC_ERR_HIP, "nmpc_loop_new: hipMalloc", e); }
+    // route tables: x_ref | y_ref | theta_ref | vertices | brake velocities | brake distances
+    std::vector<double> tab(ntab);
+    double *q = tab.data();
+    std::memcpy(q, r->x_ref, 8 * (size_t)r->n_ref); q += r->n_ref;
+    std::memcpy(q, r->y_ref, 8 * (size_t)r->n_ref); q += r->n_ref;
+    std::memcpy(q, r->theta_ref, 8 * (size_t)r->n_ref); q += r->n_ref;
+    if (r->n_vert) std::memcpy(q, r->vert_xy, 16 * (size_t)r->n_vert);
+    q += 2 * r->n_vert;
+    std::memcpy(q, r->brake_vel, 8 * (size_t)r->n_brake); q += r->n_brake;
+    std::memcpy(q, r->brake_dist, 8 * (size_t)r->n_brake);
+    e = hipMemcpy(l->d_tab, tab.data(), ntab * 8, hipMemcpyHostToDevice);
+    a.xr = l->d_tab; a.yr = a.xr + r->n_ref; a.thr = a.yr + r->n_ref; a.vert = a.thr + r->n_ref;
+    a.bv = a.vert + 2 * r->n_vert; a.bd = a.bv + r->n_brake;
+    if (e == hipSuccess && K) e = hipMemcpy(l->d_dynpar, dyn, (size_t)B * K * 8 * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(l->d_state, starts, (size_t)B * 3 * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && l->d_traj) e = hipMemcpy(l->d_traj, starts, (size_t)B * 3 * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(l->d_last_u, 0, (size_t)B * 2 * 8);
+    if (e == hipSuccess) e = hipMemset(l->d_U, 0, (size_t)B * a.n_u * 8);
+    if (e == hipSuccess) e = hipMemset(l->d_Y, 0, (size_t)B * n1 * 8);
+    if (e == hipSuccess) e = idx0 ? hipMemcpy(l->d_idx, idx0, (size_t)B * sizeof(int), hipMemcpyHostToDevice)
+                                  : hipMemset(l->d_idx, 0, (size_t)B * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(l->d_done, 0, (size_t)B);
+    if (e == hipSuccess) e = hipMemset(l->d_st, 0, (size_t)B * sizeof(nmpc_status));
+    if (e == hipSuccess && ndynrow) {          // padding block: zeros with unit radii (path_generator.py:274-280)
+        std::vector<double> pad((size_t)B * ndynrow, 0.0);
+        for (size_t i = 0; i < pad.size(); i += 5) { pad[i + 2] = 1.0; pad[i + 3] = 1.0; }
+        e = hipMemcpy(l->d_dyn[0], pad.data(), pad.size() * 8, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { nmpc_loop_free(l); return fail(h, NMPC_ERR_HIP, "nmpc_loop_new: initialisation", e); }
+    a.dynpar = l->d_dynpar; a.state = l->d_state; a.last_u = l->d_last_u; a.idx = l->d_idx;
+    a.P = l->d_P; a.U = l->d_U; a.done = l->d_done; a.traj = l->d_traj; a.traj_row = 1;
+    *out = l;
+    return NMPC_OK;
+}
+
+void nmpc_loop_free(nmpc_loop *l)
+{
+    if (!l) return;
+    (void)hipSetDevice(l->h->device);
+    (void)hipFree(l->d_tab); (void)hipFree(l->d_dynpar); (void)hipFree(l->d_state); (void)hipFree(l->d_last_u);
+    (void)hipFree(l->d_dyn[0]); (void)hipFree(l->d_dyn[1]); (void)hipFree(l->d_P); (void)hipFree(l->d_U);
+    (void)hipFree(l->d_Y); (void)hipFree(l->d_idx); (void)hipFree(l->d_done); (void)hipFree(l->d_st);
+    (void)hipFree(l->d_traj);
+    delete l;
+}
+
+int nmpc_loop_step(nmpc_loop *l, void *stream)
+{
+    if (!l) return NMPC_ERR_BAD_ARG;
+    nmpc_handle *h = l->h;
+    if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
+    if (l->max_steps > 0 && l->steps >= l->max_steps) return fail(h, NMPC_ERR_BAD_ARG, "trajectory buffer is full");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(h, hipSetDevice(h->device));
+    nmpc::LoopArgs &a = l->a;
+    const int cur = l->steps & 1;
+    a.dyn_in = l->d_dyn[cur];
+    a.dyn_out = l->d_dyn[cur ^ 1];
+    hipLaunchKernelGGL(nmpc::nmpc_loop_assemble_kernel, dim3(a.B), dim3(64), 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    // warm start: previous controls and multipliers, penalty back to its initial value (the server's behaviour)
+    const int rc = nmpc_solve_batch_device(h, a.B, l->d_P, l->d_U, l->d_Y, nullptr, l->d_Y, l->d_st, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nmpc::nmpc_loop_advance_kernel, dim3((a.B + 255) / 256), dim3(256), 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    a.t += a.s;
+    a.traj_row += a.s;
+    l->steps++;
+    return NMPC_OK;
+}
+
+int nmpc_loop_read(nmpc_loop *l, double *state, double *last_u, int32_t *idx, uint8_t *done, nmpc_status *status)
+{
+    if (!l) return NMPC_ERR_BAD_ARG;
+    nmpc_handle *h = l->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const size_t B = (size_t)l->a.B;
+    if (state) HIP_TRY(h, hipMemcpy(state, l->d_state, B * 3 * 8, hipMemcpyDeviceToHost));
+    if (last_u) HIP_TRY(h, hipMemcpy(last_u, l->d_last_u, B * 2 * 8, hipMemcpyDeviceToHost));
+    if (idx) HIP_TRY(h, hipMemcpy(idx, l->d_idx, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (done) HIP_TRY(h, hipMemcpy(done, l->d_done, B, hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(h, hipMemcpy(status, l->d_st, B * sizeof(nmpc_status), hipMemcpyDeviceToHost));
+    return NMPC_OK;
+}
+
+int nmpc_loop_params(nmpc_loop *l, double *p, double *u, double *y)
+{
+    if (!l) return NMPC_ERR_BAD_ARG;
+    nmpc_handle *h = l->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const size_t B = (size_t)l->a.B;
+    if (p) HIP_TRY(h, hipMemcpy(p, l->d_P, B * l->a.n_p * 8, hipMemcpyDeviceToHost));
+    if (u) HIP_TRY(h, hipMemcpy(u, l->d_U, B * l->a.n_u * 8, hipMemcpyDeviceToHost));
+    if (y) HIP_TRY(h, hipMemcpy(y, l->d_Y, B * (size_t)nmpc_n1(&h->pb) * 8, hipMemcpyDeviceToHost));
+    return NMPC_OK;
+}
+
+int nmpc_loop_trajectory(nmpc_loop *l, double *rows, int max_rows)
+{
+    if (!l || !rows) return NMPC_ERR_BAD_ARG;
+    nmpc_handle *h = l->h;
+    if (!l->d_traj) return fail(h, NMPC_ERR_BAD_ARG, "the loop was created without a trajectory buffer");
+    const int nrows = l->steps * l->a.s + 1;
+    if (max_rows < nrows) return fail(h, NMPC_ERR_BAD_ARG, "trajectory does not fit");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(rows, l->d_traj, (size_t)nrows * l->a.B * 3 * 8, hipMemcpyDeviceToHost));
+    return nrows;
 }
 
 // ---- arithmetic primitives, for bit-level checks against the oracle ----

@@ -205,9 +205,12 @@ class VectorizedRecedingHorizon:
     arrays ``(p1 [B, K, 2], p2 [B, K, 2], freq [B, K], rx [B, K], ry [B, K], angle [B, K])``.
     """
 
-    def __init__(self, route: harness.Route, starts, dyn_obs=None):
+    def __init__(self, route: harness.Route, starts, dyn_obs=None, sincos=None):
         cfg = self.cfg = route.cfg
         self.route = route
+        # sin / cos used by the state advance and the obstacle predictor: libm's (as the reference) unless
+        # a replacement is given -- the device loop's bit-level mirror passes the kernels' own sin / cos
+        self.sincos = sincos if sincos is not None else (lambda x: (np.sin(x), np.cos(x)))
         self.B = B = len(starts)
         self.state = np.array(starts, dtype=np.float64).reshape(B, 3)
         self.traj = [self.state.copy()]
@@ -237,7 +240,7 @@ class VectorizedRecedingHorizon:
         cfg = self.cfg
         p1, p2, freq, rx, ry, ang = self.dyn_obs
         times = np.linspace(t0, t0 + horizon * cfg.ts, horizon)                       # (:204)
-        s = np.abs(np.sin(freq[:, :, None] * times[None, None, :]))                  # [B, K, H]
+        s = np.abs(self.sincos(freq[:, :, None] * times[None, None, :])[0])        # [B, K, H]
         pos = s[..., None] * p1[:, :, None, :] + (1 - s[..., None]) * p2[:, :, None, :]
         pad = cfg.vehicle_width / 2 + cfg.vehicle_margin
         out = np.empty(pos.shape[:3] + (5,))
@@ -325,7 +328,8 @@ class VectorizedRecedingHorizon:
             v, w = U[:, i * cfg.nu], U[:, 1 + i * cfg.nu]
             th = st[:, 2]
             # per robot: x + ts*(v*cos(theta)) with math.cos -> np.cos is the same libm call
-            st = np.stack([st[:, 0] + cfg.ts * (v * np.cos(th)), st[:, 1] + cfg.ts * (v * np.sin(th)),
+            sn, cs = self.sincos(np.ascontiguousarray(th))
+            st = np.stack([st[:, 0] + cfg.ts * (v * cs), st[:, 1] + cfg.ts * (v * sn),
                            th + cfg.ts * w], axis=1)
             self.traj.append(st.copy())
         self.state = st
@@ -341,3 +345,104 @@ class VectorizedRecedingHorizon:
         self.U, self.Y = U, Y
         self.advance(U)
         return P, st
+
+
+class DeviceRecedingHorizon:
+    """``VectorizedRecedingHorizon`` with everything on the GPU: parameter assembly, the batched solve
+    and the state advance are kernels of libnmpc_hip.so (``nmpc_loop_*``, include/nmpc_solver.h), and
+    nothing crosses PCIe between steps.  Same quantities, same order of operations as the host class;
+    sin / cos are the kernels' own (tests/test_gpu_loop.py compares bit for bit against the host class
+    given the same sin / cos).
+
+    ``solver`` is the ``BatchSolver`` whose handle runs the solves; ``dyn_obs`` as in
+    ``VectorizedRecedingHorizon``; ``max_steps`` > 0 records the trajectory on device; ``idx0`` = the
+    reference sample each robot starts at (default 0, as the reference).
+    """
+
+    def __init__(self, solver, route: harness.Route, starts, dyn_obs=None, max_steps: int = 0, idx0=None):
+        import ctypes as C
+        from . import _lib
+        cfg = self.cfg = route.cfg
+        self.solver, self.route, self.lib = solver, route, solver.lib
+        self.B = B = len(starts)
+        self.t = 0
+        self.steps = 0
+        starts = np.ascontiguousarray(np.array(starts, dtype=np.float64).reshape(B, 3))
+        K = 0 if dyn_obs is None else dyn_obs[0].shape[1]
+        dyn = None
+        if K:
+            p1, p2, freq, rx, ry, ang = dyn_obs
+            dyn = np.ascontiguousarray(np.concatenate(
+                [p1, p2, freq[..., None], rx[..., None], ry[..., None], ang[..., None]], axis=2), dtype=np.float64)
+            assert dyn.shape == (B, K, 8)
+        r = _lib.NmpcRoute()
+        keep = []                                              # arrays the struct points to, until nmpc_loop_new returns
+
+        def arr(v):
+            a = np.ascontiguousarray(v, dtype=np.float64)
+            keep.append(a)
+            return _lib.as_dp(a)
+        vert = np.array(route.vertices, dtype=np.float64).reshape(-1, 2)
+        r.n_ref, r.n_vert, r.n_brake = len(route.x_ref), len(vert), len(route.brake_velocities)
+        r.num_steps_taken = cfg.num_steps_taken
+        r.x_ref, r.y_ref, r.theta_ref = arr(route.x_ref), arr(route.y_ref), arr(route.theta_ref)
+        r.vert_xy = arr(vert) if len(vert) else None
+        r.brake_vel, r.brake_dist = arr(route.brake_velocities), arr(route.brake_distances)
+        r.end = (C.c_double * 3)(*[float(v) for v in route.end])
+        r.base_speed, r.radius = float(route.base_speed), float(route.radius)
+        r.dyn_pad = cfg.vehicle_width / 2 + cfg.vehicle_margin
+        r.weights = (C.c_double * 10)(*cfg.weights())
+        h = C.c_void_p()
+        i0 = None if idx0 is None else np.ascontiguousarray(idx0, dtype=np.int32)
+        solver._check(self.lib.nmpc_loop_new(solver._h, C.byref(r), B, _lib.as_dp(starts),
+                                             None if i0 is None else i0.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             K, _lib.as_dp(dyn), int(max_steps), C.byref(h)))
+        self._l = h
+        self.max_steps = int(max_steps)
+
+    def close(self):
+        if getattr(self, "_l", None):
+            self.lib.nmpc_loop_free(self._l)
+            self._l = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, stream=None):
+        """Enqueue one assemble -> solve -> advance; returns without synchronising."""
+        self.solver._check(self.lib.nmpc_loop_step(self._l, stream))
+        self.t += self.cfg.num_steps_taken
+        self.steps += 1
+
+    def read(self):
+        """-> (state [B,3], last_u [B,2], idx [B], done [B] bool, status [B]) after synchronising."""
+        import ctypes as C
+        from . import _lib
+        B = self.B
+        state, last_u = np.empty((B, 3)), np.empty((B, 2))
+        idx, done = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.uint8)
+        st = np.empty(B, dtype=_lib.STATUS_DTYPE)
+        self.solver._check(self.lib.nmpc_loop_read(self._l, _lib.as_dp(state), _lib.as_dp(last_u),
+                                                   idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   done.ctypes.data_as(C.POINTER(C.c_uint8)), st.ctypes.data))
+        return state, last_u, idx, done.astype(bool), st
+
+    def params(self):
+        """-> (P [B,n_p] of the last step, U [B,n_u], Y [B,n1])."""
+        from . import _lib
+        P, U, Y = np.empty((self.B, self.cfg.n_p)), np.empty((self.B, self.cfg.n_u)), np.empty((self.B, self.cfg.n1))
+        self.solver._check(self.lib.nmpc_loop_params(self._l, _lib.as_dp(P), _lib.as_dp(U), _lib.as_dp(Y)))
+        return P, U, Y
+
+    def trajectory(self):
+        """-> [rows, B, 3]: the start poses and every pose reached so far (needs ``max_steps`` > 0)."""
+        from . import _lib
+        rows = self.steps * self.cfg.num_steps_taken + 1
+        T = np.empty((rows, self.B, 3))
+        n = self.lib.nmpc_loop_trajectory(self._l, _lib.as_dp(T), rows)
+        if n < 0:
+            self.solver._check(n)
+        return T

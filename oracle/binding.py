@@ -70,6 +70,7 @@ class Oracle:
         self.lib.orc_tree_sum.restype = C.c_double
         self.lib.orc_tree_sum.argtypes = [C.POINTER(C.c_double), C.c_int]
         self.lib.orc_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        self.lib.orc_sincos_n.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 3
         self.lib.orc_eval.argtypes = [C.POINTER(OrcProblem), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.c_double] + [C.POINTER(C.c_double)] * 5
         self.lib.orc_solve_batch.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcOpts), C.c_int,
@@ -80,6 +81,14 @@ class Oracle:
         self.n_p = self.lib.orc_n_p(C.byref(self.pb))
         self.n1 = self.lib.orc_n1(C.byref(self.pb))
         self.n2 = self.lib.orc_n2(C.byref(self.pb))
+
+    def sincos_array(self, x):
+        """(sin, cos) of an array with the canonical sin/cos of the kernels (not libm's)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        sn, cs = np.empty_like(x), np.empty_like(x)
+        dp = C.POINTER(C.c_double)
+        self.lib.orc_sincos_n(x.size, x.ctypes.data_as(dp), sn.ctypes.data_as(dp), cs.ctypes.data_as(dp))
+        return sn, cs
 
     def sincos(self, x):
         s, c = C.c_double(), C.c_double()

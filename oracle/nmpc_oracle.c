@@ -81,6 +81,11 @@ void orc_sincos(double x, double *s, double *c)
     *c = co;
 }
 
+void orc_sincos_n(int n, const double *x, double *s, double *c)
+{
+    for (int i = 0; i < n; ++i) orc_sincos(x[i], s + i, c + i);
+}
+
 /* padded horizon: 32 stages for N <= 32, else 64 */
 static int pad_pow2(int n) { return n <= 32 ? 32 : 64; }
 

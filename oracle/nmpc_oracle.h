@@ -87,6 +87,7 @@ int orc_solve_batch(const orc_problem *pb, const orc_opts *opts, int B, const do
 
 /* primitives, exported so the GPU's can be checked bit-for-bit */
 void orc_sincos(double x, double *s, double *c);
+void orc_sincos_n(int n, const double *x, double *s, double *c);     /* the same, element by element */
 double orc_tree_sum(const double *v, int n);
 
 #ifdef __cplusplus
