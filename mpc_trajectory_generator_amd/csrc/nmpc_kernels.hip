@@ -101,6 +101,7 @@ struct DynStage {
 // configs/default.yaml (N_hor 20, Nobs 10, Ndynobs 3), for which loops unroll and LDS offsets fold.
 struct ShapeAny { static constexpr int N = 0, NOBS = -1, NDYN = -1; };
 struct ShapeDefault { static constexpr int N = 20, NOBS = 10, NDYN = 3; };
+struct ShapeNobs50 { static constexpr int N = 20, NOBS = 50, NDYN = 3; };     // BASELINE config 3
 template <class SH> __device__ __forceinline__ int shape_N(const KArgs &a) { if constexpr (SH::N > 0) return SH::N; else return a.pb.N; }
 template <class SH> __device__ __forceinline__ int shape_nobs(const KArgs &a) { if constexpr (SH::NOBS >= 0) return SH::NOBS; else return a.pb.nobs; }
 template <class SH> __device__ __forceinline__ int shape_ndyn(const KArgs &a) { if constexpr (SH::NDYN >= 0) return SH::NDYN; else return a.pb.ndyn; }
@@ -298,7 +299,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     {
         const lds_double *ob = L + a.map.obs;
         const int nobs4 = (nobs + 3) & ~3;
-#pragma unroll(SH::NOBS >= 0 ? 16 : 1)
+#pragma unroll(SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1)
         for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, VALU only
             double od[12];
 #pragma unroll
@@ -899,6 +900,7 @@ struct nmpc_handle {
     LdsMap map;
     int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one)
     bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
+    bool shape_nobs50;     // ... == ShapeNobs50
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
     int *d_order;              // launch order (hard-looking instances first)
@@ -990,8 +992,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     }
     h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
+    h->shape_nobs50 = pb->N == nmpc::ShapeNobs50::N && pb->nobs == nmpc::ShapeNobs50::NOBS &&
+                      pb->ndyn == nmpc::ShapeNobs50::NDYN;
     if (const char *env = getenv("NMPC_SHAPE")) {              // experiments: force the run-time-shape kernel
-        if (!strcmp(env, "any")) h->shape_default = false;
+        if (!strcmp(env, "any")) h->shape_default = h->shape_nobs50 = false;
     }
     h->map = make_map(*pb, op.lbfgs_memory, h->P);
     h->d_queue = nullptr;
@@ -1037,7 +1041,9 @@ const char *nmpc_last_error(const nmpc_handle *h) { return h ? h->err.c_str() : 
 const char *nmpc_kernel_name(const nmpc_handle *h)
 {
     if (!h) return "";
-    if (h->P == 20) return h->shape_default ? "nmpc_solve_tri_kernel<ShapeDefault>" : "nmpc_solve_tri_kernel<ShapeAny>";
+    if (h->P == 20)
+        return h->shape_default ? "nmpc_solve_tri_kernel<ShapeDefault>"
+                                : (h->shape_nobs50 ? "nmpc_solve_tri_kernel<ShapeNobs50>" : "nmpc_solve_tri_kernel<ShapeAny>");
     return h->P == 32 ? "nmpc_solve_dual_kernel" : "nmpc_solve_kernel<64>";
 }
 
@@ -1077,6 +1083,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
     if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20 && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
