@@ -173,7 +173,9 @@ def main():
         "p50_inner_iters": float(np.median(st["num_inner_iterations"])),
         "p99_inner_iters": float(np.percentile(st["num_inner_iterations"], 99)),
         "max_inner_iters": int(st["num_inner_iterations"].max()),
-        "roofline": {"bound": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
+        # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s);
+        # the kernel issues no MFMA -- "bound_detail" says what actually limits it
+        "roofline": {"bound": "mfma", "bound_detail": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
                      "traffic": None, "kernel": solver.kernel_name, "kernel_ms": kern_ms,
                      "flops_per_launch": flops,
