@@ -65,7 +65,7 @@ assert STATUS_DTYPE.itemsize == 72
 
 def build_library(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 the kernels in-tree (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("nmpc_kernels.hip", "nmpc_device.h", "nmpc_solve_dual.h", "nmpc_solve_tri.h", "nmpc_loop.h", "Makefile")]
+    srcs = [os.path.join(_CSRC, f) for f in ("nmpc_kernels.hip", "nmpc_device.h", "nmpc_solve_dual.h", "nmpc_solve_tri.h", "nmpc_solve_hyb.h", "nmpc_loop.h", "Makefile")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "nmpc_solver.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

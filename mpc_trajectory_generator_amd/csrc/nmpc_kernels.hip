@@ -810,6 +810,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 
 #include "nmpc_solve_dual.h"
 #include "nmpc_solve_tri.h"
+#include "nmpc_solve_hyb.h"
 #include "nmpc_loop.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -901,6 +902,7 @@ struct nmpc_handle {
     int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one)
     bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
     bool shape_nobs50;     // ... == ShapeNobs50
+    bool hybrid;           // P == 20: solver state in the two-half layout, evaluation in the tri layout (nmpc_solve_hyb.h)
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
     int *d_order;              // launch order (hard-looking instances first)
@@ -960,13 +962,13 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     mp.obs = o; o += 3 * (pb.nobs + 4);
     mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / tri kernels)
     mp.rho = o; o += m;
-    const int cols = P == 20 ? 24 : P;                // nmpc::lay_cols
+    const int cols = P == 20 ? 32 : P;                // >= nmpc::lay_cols; the hybrid kernel parks 32 state-layout columns
     mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * cols;
     o = (o + 1) & ~1;
     mp.vec = o; o += 6 * 2 * cols;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
-    mp.S = o;   o += 2 * pb.N * m;
-    mp.Y = o;   o += 2 * pb.N * m;
+    mp.S = o;   o += 2 * (pb.N + 1) * m;        // (+1: the hybrid kernel keeps an all-zero column per slot)
+    mp.Y = o;   o += 2 * (pb.N + 1) * m;
     mp.total = (o + 1) & ~1;
     return mp;
 }
@@ -987,8 +989,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true;
     h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : 64);
-    if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments: force the two-point layout
+    h->hybrid = true;
+    if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments: force the two-point layout / the all-tri kernel
         if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
+        if (!strcmp(env, "tri")) h->hybrid = false;
     }
     h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
@@ -1041,6 +1045,9 @@ const char *nmpc_last_error(const nmpc_handle *h) { return h ? h->err.c_str() : 
 const char *nmpc_kernel_name(const nmpc_handle *h)
 {
     if (!h) return "";
+    if (h->P == 20 && h->hybrid)
+        return h->shape_default ? "nmpc_solve_hyb_kernel<ShapeDefault>"
+                                : (h->shape_nobs50 ? "nmpc_solve_hyb_kernel<ShapeNobs50>" : "nmpc_solve_hyb_kernel<ShapeAny>");
     if (h->P == 20)
         return h->shape_default ? "nmpc_solve_tri_kernel<ShapeDefault>"
                                 : (h->shape_nobs50 ? "nmpc_solve_tri_kernel<ShapeNobs50>" : "nmpc_solve_tri_kernel<ShapeAny>");
@@ -1082,7 +1089,10 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
-    if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
+    if (h->P == 20 && h->hybrid && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20 && h->hybrid && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20 && h->hybrid) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 20 && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);

@@ -1,0 +1,517 @@
+// nmpc_solve_hyb.h -- the N_hor <= 20 solver: ONE problem instance per wavefront, THREE query points
+// per pass, TWO lane layouts.
+//
+// The evaluation of psi runs in the "tri" layout of nmpc_device.h (rows 0..2 of the wave hold stages
+// 0..15 of query points 0..2, the quads of row 3 stages 16..19): three points per pass.  The solver
+// state (u, grad, half step, residual, direction, L-BFGS ring) lives in the layout of the two-point
+// kernel: stage t at lane t of BOTH 32-lane halves, so every reduction of the PANOC / L-BFGS code is a
+// pure DPP + permlane tree (no LDS round trip; the tri layout's row <-> tail exchange costs one per
+// reduction, and the two-loop recursion alone chains twenty of them per iteration).  Query points are
+// carried from the state layout to the evaluation layout, and gradients back, with ds_bpermute:
+//   X = per-half point (half 0 / half 1 prepare different points), Y = a third point known to both.
+//   initialisation   X = (u | u + h)                 Y = u
+//   iteration >= 1   X = (u_bar | u+(tau = 1))       Y = u+(tau = 1/2)
+//   line search      X = (u+(tau) | u+(tau/2))       Y = u+(tau/4)
+// Trials are consumed in order and the first accepted one ends the iteration, exactly as the
+// sequential line search would; evaluations past the accepted trial are discarded and not counted.
+// Same results and counters as nmpc_solve_tri.h, nmpc_solve_dual.h and the sequential oracle.
+#pragma once
+
+namespace nmpc {
+
+// gradient pair of query point k's evaluation, delivered to the state layout (zero beyond the horizon)
+#define NMPC_FETCH_GRAD(SRC, OV, OW)                                           \
+    do {                                                                       \
+        const double fv_ = lane_get(egv, (SRC)), fw_ = lane_get(egw, (SRC));   \
+        OV = in ? fv_ : 0.0; OW = in ? fw_ : 0.0;                              \
+    } while (0)
+
+// gradient step x - gamma g and its projection on U (lanes beyond the horizon stay zero)
+#define NMPC_HALF_STEP(xv, xw)                                                 \
+    do {                                                                       \
+        const double s1_ = fma(-gamma, gv, (xv)), s2_ = fma(-gamma, gw, (xw)); \
+        hv = ina ? clampd(s1_, vmin, vmax) : s1_;                              \
+        hw = ina ? clampd(s2_, -wmax, wmax) : s2_;                             \
+    } while (0)
+// FBE at the cached point; the gradient step x - gamma g is recomputed (bitwise the same value)
+#define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
+
+template <class SH>
+__global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
+{
+    constexpr int PE = 20;                      // evaluation layout: three lane groups (nmpc_device.h)
+    constexpr int P = 32, COLS = 32;            // state layout: stage t at lane t of both 32-lane halves
+    extern __shared__ double lds[];
+    lds_double *L = (lds_double *)lds;
+    const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
+    const int q = lay_group<PE>(lane), te = lay_stage<PE>(lane);
+    const int N = shape_N<SH>(a), m = a.op.lbfgs_memory;
+    const bool in = t < N, ina = in;            // state layout: lanes beyond the horizon hold zeros
+    const bool ine = te < N;                    // evaluation layout: a real stage
+    // with a 20-stage horizon every stage lane of the evaluation layout is inside it (lanes 60..63 may
+    // hold don't-care values: no cross-lane operation lets them into other lanes)
+    constexpr bool FULL = SH::N == PE;
+    const bool inea = FULL ? true : ine;
+    const int f2off = a.map.f2 + q * (a.n2 + 1);
+    // evaluation-layout lane that holds stage t of query point 0 / 1 / 2 (state lanes beyond the horizon: themselves)
+    const int src0 = in ? lay_lane<PE>(0, t) : lane, src1 = in ? lay_lane<PE>(1, t) : lane, src2 = in ? lay_lane<PE>(2, t) : lane;
+    // state-layout lane that holds this evaluation lane's query point: X of half q (points 0, 1), Y (point 2)
+    const int zsrcX = ine ? (q < 2 ? 32 * q + te : te) : lane, zsrcY = ine ? te : lane;
+    // L-BFGS ring: N + 1 columns per slot, the last one all zeros -- lanes beyond the horizon read it
+    const int NS = N + 1, tt = in ? t : N;
+    lds_double2 *LS = (lds_double2 *)(L + a.map.S);
+    lds_double2 *LY = (lds_double2 *)(L + a.map.Y);
+    lds_double *Lrho = L + a.map.rho;
+    lds_double2 *Los = (lds_double2 *)(L + a.map.vec) + t;      // parked pairs, one column per stage
+    lds_double2 *Log = Los + COLS, *Lq = Los + 2 * COLS, *Lyp = Los + 3 * COLS;
+    lds_double2 *LypE = (lds_double2 *)(L + a.map.vec) + 3 * COLS + te;      // the same columns, by evaluation lane
+    lds_double2 *Ly = (lds_double2 *)(L + a.map.vec) + 4 * COLS + te;        // multipliers y (read by every evaluation)
+    lds_double *Lvr = L + a.map.vec + 2 * 5 * COLS + te;                     // reference speed of this stage
+    if (lane < MAXMEM) { LS[lane * NS + N] = dbl2{0.0, 0.0}; LY[lane * NS + N] = dbl2{0.0, 0.0}; }
+    NMPC_WAVE_SYNC();
+    const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
+    const unsigned max_inner = (unsigned)a.op.max_inner;
+    lds_double *Lpar = L + a.map.par;
+#define pk_eps_nu Lpar[0]
+#define pk_dy_norm Lpar[1]
+#define pk_f2_norm Lpar[2]
+#define pk_dy_norm_plus Lpar[3]
+#define pk_f2_norm_plus Lpar[4]
+#define pk_last_fpr Lpar[5]
+#define pk_last_cost Lpar[6]
+#define pk_norm_h Lpar[7]
+#define pk_Lc Lpar[8]
+#define pk_H0 Lpar[9]
+#define pk_sigma Lpar[10]
+#define pk_c_lip Lpar[11]
+
+    for (;;) {
+        // ------------------------------------------------------------------ next instance from the queue
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(a.queue, 1u);
+        nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+        if (nxt >= (unsigned)a.B) break;
+        const int inst = a.order ? a.order[nxt] : (int)nxt;
+
+        double vref_;
+        DynStage dyn;
+        prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
+        *Lvr = vref_;
+
+        // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
+        const double *u0 = a.u + (size_t)inst * a.n_u;
+        double uv = in ? u0[2 * t] : 0.0, uw = in ? u0[2 * t + 1] : 0.0;
+        {
+            const double yv0 = (a.y0 && ine) ? a.y0[(size_t)inst * a.n1 + te] : 0.0;
+            const double yw0 = (a.y0 && ine) ? a.y0[(size_t)inst * a.n1 + N + te] : 0.0;
+            *LypE = dbl2{yv0, yw0};
+            *Ly = dbl2{yv0, yw0};
+        }
+        *Lq = dbl2{0.0, 0.0};                    // gradient_u_previous (AKKT residual) starts at zero
+        double gv = 0, gw = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
+        double pv = 0, pw = 0;                    // line-search trial point being consumed
+        double xv = 0, xw = 0;                    // query point X of THIS half (-> evaluation points 0 and 1)
+        double yqv = 0, yqw = 0;                  // query point Y (-> evaluation point 2)
+        bool need_grad = true;
+        double cost = 0, gamma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0;
+        pk_Lc = 0.0; pk_sigma = 0.0; pk_H0 = 1.0;
+        double fbe_u = 0;                         // FBE at the current iterate, valid while fbe_ok (an accepted
+        bool fbe_ok = false;                      // trial's FBE is the next iteration's: same operands, same bits)
+        int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
+        bool lb_first = true;
+        // tentative L-BFGS update of the current iteration (committed when the Lipschitz test passes)
+        int n_active = 0, n_head = 0;
+        bool n_first = true, n_take_old = false;
+        double n_H0 = 1;
+        unsigned num_iter = 0;
+        const double c0 = a.c0 ? a.c0[inst] : 0.0;
+        double pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
+        double cbar_inv = 1.0 / fmax(pen_c, 1.0);          // 1 / max(c, 1), refreshed when c changes
+        pk_c_lip = 0.0;                                     // 0.95 / (2 gamma), refreshed when gamma changes
+        // scalars touched once per inner solve / outer iteration are parked in LDS (every lane writes the
+        // same value) instead of occupying a VGPR pair each for the whole solve
+        pk_eps_nu = a.op.initial_tolerance;
+        pk_dy_norm = 0.0; pk_f2_norm = 0.0; pk_dy_norm_plus = DBL_MAX; pk_f2_norm_plus = 0.0; pk_last_fpr = 0.0; pk_last_cost = 0.0; pk_norm_h = 0.0;
+        int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
+        unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
+
+        // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
+        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
+        bool running = true;
+#ifdef NMPC_PROFILE
+        { extern __shared__ long long nmpc_prof_lds[]; if (lane < 16) nmpc_prof_lds[4096 + lane] = 0; }
+        long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
+#define NMPC_TICK(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
+        NMPC_TICK(tk0);
+#endif
+
+        for (;;) {
+            // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
+            if (f_back) {
+                f_back = false;
+                lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
+                fbe_ok = false;
+                pk_Lc *= 2.0; gamma /= 2.0;
+                pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                NMPC_HALF_STEP(uv, uw);
+                rv = uv - hv; rw = uw - hw;
+                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                norm_r = sqrt(nr2);
+                lip_it++;
+                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+            }
+            // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1) | (tau/4, ls_n+2)
+            if (f_trials) {
+                f_trials = false;
+                const double th_ = h == 0 ? tau : tau / 2.0, omt = 1.0 - th_;
+                xv = fma(-th_, dv, fma(-omt, rv, uv));
+                xw = fma(-th_, dw, fma(-omt, rw, uw));
+                const double t4_ = tau / 4.0, om4_ = 1.0 - t4_;
+                yqv = fma(-t4_, dv, fma(-om4_, rv, uv));
+                yqw = fma(-t4_, dw, fma(-om4_, rw, uw));
+                need_grad = true; state = D_LS;
+            }
+            // ---------------------------------------------------------------- an iteration finished
+            if (f_end) {
+                f_end = false;
+                iteration++;
+                // OpEn: while step() && num_iter < max_iter { num_iter++ }
+                if (!(num_iter < max_inner)) f_done = true;
+                else { num_iter++; f_begin = true; }
+            }
+            // ---------------------------------------------------------------- start of a PANOC step
+            if (f_begin) {
+                f_begin = false;
+                rv = uv - hv; rw = uw - hw;
+                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                norm_r = sqrt(nr2);
+                bool exit_now = false;
+                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test
+                    const dbl2 q_ = *Lq;
+                    const double a1 = rv / gamma + (gv - q_.x), a2 = rw / gamma + (gw - q_.y);
+                    exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < pk_eps_nu);
+                }
+                if (exit_now) {
+                    f_done = true;
+                } else if (iteration == 0) {
+                    // psi and grad psi at u_bar serve both the Lipschitz test and the first FB step
+                    lip_it = 0;
+                    xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_LIP;
+                } else {
+                    lip_it = 0;
+                    // ---- tentative L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
+                    n_first = lb_first; n_head = lb_head; n_active = lb_active; n_H0 = pk_H0; n_take_old = false;
+                    if (lb_first) {
+                        n_first = false; n_take_old = true;
+                    } else {
+                        const dbl2 os_ = *Los, og_ = *Log;
+                        const double s1 = uv - os_.x, s2 = uw - os_.y, y1 = rv - og_.x, y2 = rw - og_.y;
+                        const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
+                        bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
+                        if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
+                        if (__any(ok)) {
+                            n_take_old = true;
+                            n_head = lb_head == 0 ? m - 1 : lb_head - 1;
+                            if (in && h == 0) { LS[n_head * NS + t] = dbl2{s1, s2}; LY[n_head * NS + t] = dbl2{y1, y2}; }
+                            if (lane == 0) Lrho[n_head] = 1.0 / ys;
+                            n_H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
+                            if (n_active < m) n_active++;
+                            NMPC_WAVE_SYNC();
+                        }
+                    }
+                    // ---- d = H r, two-loop recursion over the tentative buffer ----
+                    dv = rv; dw = rw;
+                    if (n_active == MAXMEM && m == MAXMEM) {
+                        // full buffer (the steady state): branch-free, all pairs addressed statically from the head
+                        double alpha[MAXMEM];
+#pragma unroll
+                        for (int k = 0; k < MAXMEM; ++k) {
+                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
+                            const dbl2 s_ = LS[slot * NS + tt], y_ = LY[slot * NS + tt];
+                            const double al = Lrho[slot] * hdot<P>(s_.x, s_.y, dv, dw, lane);
+                            alpha[k] = al;
+                            dv = fma(-al, y_.x, dv); dw = fma(-al, y_.y, dw);
+                        }
+                        dv = n_H0 * dv; dw = n_H0 * dw;
+#pragma unroll
+                        for (int k = MAXMEM - 1; k >= 0; --k) {
+                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
+                            const dbl2 s_ = LS[slot * NS + tt], y_ = LY[slot * NS + tt];
+                            const double be = Lrho[slot] * hdot<P>(y_.x, y_.y, dv, dw, lane);
+                            const double ab = alpha[k] - be;
+                            dv = fma(ab, s_.x, dv); dw = fma(ab, s_.y, dw);
+                        }
+                    } else if (n_active > 0) {
+                        // pair k lives in ring slot (n_head + k) mod m; each trip fetches the NEXT pair from
+                        // LDS before it reduces the current one, so the LDS latency hides under the reduction
+                        double alpha[MAXMEM];
+                        int slot = n_head;
+                        dbl2 sc_ = LS[slot * NS + tt], yc_ = LY[slot * NS + tt];
+                        double rc_ = Lrho[slot];
+#pragma unroll
+                        for (int k = 0; k < MAXMEM; ++k) {
+                            alpha[k] = 0.0;
+                            if (k < n_active) {
+                                dbl2 sn_ = {0.0, 0.0}, yn_ = {0.0, 0.0};
+                                double rn_ = 0.0;
+                                if (k + 1 < n_active) {
+                                    slot = slot + 1 == m ? 0 : slot + 1;
+                                    sn_ = LS[slot * NS + tt]; yn_ = LY[slot * NS + tt]; rn_ = Lrho[slot];
+                                }
+                                const double al = rc_ * hdot<P>(sc_.x, sc_.y, dv, dw, lane);
+                                alpha[k] = al;
+                                dv = fma(-al, yc_.x, dv); dw = fma(-al, yc_.y, dw);
+                                if (k + 1 < n_active) { sc_ = sn_; yc_ = yn_; rc_ = rn_; }
+                            }
+                        }
+                        dv = n_H0 * dv; dw = n_H0 * dw;
+                        // (sc_, yc_, rc_) now hold the oldest pair, k = n_active - 1; walk back to the newest
+#pragma unroll
+                        for (int k = MAXMEM - 1; k >= 0; --k) {
+                            if (k < n_active) {
+                                dbl2 sn_ = {0.0, 0.0}, yn_ = {0.0, 0.0};
+                                double rn_ = 0.0;
+                                if (k > 0) {
+                                    slot = slot == 0 ? m - 1 : slot - 1;
+                                    sn_ = LS[slot * NS + tt]; yn_ = LY[slot * NS + tt]; rn_ = Lrho[slot];
+                                }
+                                const double be = rc_ * hdot<P>(yc_.x, yc_.y, dv, dw, lane);
+                                const double ab = alpha[k] - be;
+                                dv = fma(ab, sc_.x, dv); dw = fma(ab, sc_.y, dw);
+                                if (k > 0) { sc_ = sn_; yc_ = yn_; rc_ = rn_; }
+                            }
+                        }
+                    }
+                    if (!fbe_ok) { fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
+                    rhs_ls = fbe_u - pk_sigma * nr2;
+                    tau = 1.0; ls_n = 0;
+                    xv = h ? fma(-1.0, dv, fma(-0.0, rv, uv)) : hv;      // X: u_bar | u+(tau = 1) = u - 0 r - d
+                    xw = h ? fma(-1.0, dw, fma(-0.0, rw, uw)) : hw;
+                    yqv = fma(-0.5, dv, fma(-0.5, rv, uv));               // Y: u+(tau = 1/2)
+                    yqw = fma(-0.5, dw, fma(-0.5, rw, uw));
+                    need_grad = true; state = D_ITER;
+                }
+            }
+            // ---------------------------------------------------------------- the inner solver returned
+            if (f_done) {
+                f_done = false;
+                inner_status = num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
+                inner_total += num_iter;
+                pk_last_fpr = norm_r; pk_last_cost = cost;
+                uv = hv; uw = hw;                                        // PANOC returns the feasible half step
+                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
+                if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
+                else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
+            }
+            // ---------------------------------------------------------------- start an inner solve
+            if (f_start) {
+                f_start = false;
+                { const dbl2 y_ = *Ly; *Ly = dbl2{clampd(y_.x, -1e12, 1e12), clampd(y_.y, -1e12, 1e12)}; }      // y <- Pi_Y(y)
+                lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                // init evaluates u (points 0, 2) and u + h (point 1), h_i = max(1e-6 u_i, 1e-12)
+                const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
+                const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
+                pk_norm_h = sqrt(group_sum<P>(ina ? fma(h1, h1, h2 * h2) : 0.0, lane));
+                xv = h == 1 ? (in ? uv + h1 : 0.0) : uv;
+                xw = h == 1 ? (in ? uw + h2 : 0.0) : uw;
+                yqv = uv; yqw = uw;
+                need_grad = true; state = D_INIT;
+            }
+            if (!running) break;
+
+            // ================================================================ one pass: psi at two points
+            double psi, pen, egv = 0, egw = 0, eav, eaw;
+            n_pass++;
+            // Iteration counts are heavy-tailed: an instance that has already run long is likely the
+            // one the whole batch will end up waiting for.  Raise its wave's issue priority so that
+            // it runs at (nearly) single-wave speed while it still shares its SIMD with another wave.
+            if ((n_pass & 1023u) == 0u) {
+                const unsigned lvl = n_pass >> 11;
+                if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
+                else if (lvl == 2u) __builtin_amdgcn_s_setprio(2);
+                else if (lvl >= 3u) __builtin_amdgcn_s_setprio(3);
+            }
+#ifdef NMPC_PROFILE
+            NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
+#endif
+#ifdef NMPC_MARKS
+            asm volatile("; MARK 10");
+#endif
+            const dbl2 ycur = *Ly;
+            const double yv = ycur.x, yw = ycur.y;
+            // query points: state layout -> evaluation layout
+            const double zXv = lane_get(xv, zsrcX), zXw = lane_get(xw, zsrcX);
+            const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
+            const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
+            eval_psi<PE, SH>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+#ifdef NMPC_PROFILE
+            { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
+            NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
+#endif
+#ifdef NMPC_MARKS
+            asm volatile("; MARK 11");
+#endif
+            const double psiA = point_scalar(psi, 0), psiB = point_scalar(psi, 1), psiC = point_scalar(psi, 2);
+            // one trial of the current direction: psi, grad psi were evaluated by query point K at step tau
+#define NMPC_TAKE_TRIAL(PSI, SRC)                                                      \
+            do {                                                                       \
+                n_grad++;                                                              \
+                *Lq = dbl2{gv, gw};                  /* cache_previous_gradient */     \
+                cost = (PSI);                                                          \
+                NMPC_FETCH_GRAD((SRC), gv, gw);                                        \
+                const double omt_ = 1.0 - tau;                                         \
+                pv = fma(-tau, dv, fma(-omt_, rv, uv));                                \
+                pw = fma(-tau, dw, fma(-omt_, rw, uw));                                \
+                NMPC_HALF_STEP(pv, pw);                                                \
+                lhs = NMPC_FBE(pv, pw);                                                \
+                rejected = __any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS;    \
+                if (rejected) { tau /= 2.0; ls_n++; }                                  \
+            } while (0)
+            double lhs = 0.0;
+            bool rejected = false;
+
+            if (state == D_INIT) {
+                n_grad += 2;
+                cost = psiA;
+                NMPC_FETCH_GRAD(src0, gv, gw);
+                double g1v_, g1w_;
+                NMPC_FETCH_GRAD(src1, g1v_, g1w_);
+                const double d1 = g1v_ - gv, d2 = g1w_ - gw;
+                pk_Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / pk_norm_h;
+                gamma = GAMMA_L_COEFF / fmax(pk_Lc, MIN_LIPSCHITZ_CONSTANT);
+                pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                NMPC_HALF_STEP(uv, uw);
+                fbe_ok = false;
+                f_begin = true;
+            } else if (state == D_LIP || state == D_ITER) {
+                // Lipschitz test on psi(u_bar) (half 0).  D_LIP: sequential (iteration 0, or after a
+                // failed speculative pass; the L-BFGS buffer is empty there).  D_ITER: half 1 holds the
+                // speculative trial u+(tau = 1) on the tentative direction.
+                n_cost++;
+                const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
+                                 + pk_c_lip * nr2;
+                if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(pk_Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
+                    f_back = true;                                       // (speculation discarded)
+                } else {
+                    if (state == D_LIP) {
+                        lb_first = false; *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw};      // first pair after a reset: only remembered
+                        if (iteration == 0) {
+                            // first iteration: plain forward-backward step; psi, grad psi at u_bar are at hand
+                            n_grad++;
+                            uv = hv; uw = hw;
+                            cost = psiA;
+                            NMPC_FETCH_GRAD(src0, gv, gw);
+                            NMPC_HALF_STEP(uv, uw);
+                            fbe_ok = false;
+                            f_end = true;
+                        } else {
+                            dv = rv; dw = rw;                            // empty buffer: d = r
+                            rhs_ls = NMPC_FBE(uv, uw) - pk_sigma * nr2;
+                            tau = 1.0; ls_n = 0;
+                            f_trials = true;
+                        }
+                    } else {
+                        lb_first = n_first; lb_head = n_head; lb_active = n_active; pk_H0 = n_H0;      // commit
+                        if (n_take_old) { *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw}; }
+                        NMPC_TAKE_TRIAL(psiB, src1);                     // tau = 1
+                        if (rejected) NMPC_TAKE_TRIAL(psiC, src2);       // tau = 1/2
+                        if (rejected) f_trials = true;
+                        else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+                    }
+                }
+            } else if (state == D_LS) {
+                // points 0..2 evaluated trials (tau, ls_n), (tau/2, ls_n + 1), (tau/4, ls_n + 2)
+                NMPC_TAKE_TRIAL(psiA, src0);
+                if (rejected) NMPC_TAKE_TRIAL(psiB, src1);
+                if (rejected) NMPC_TAKE_TRIAL(psiC, src2);
+                if (rejected) f_trials = true;
+                else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+            } else {    // D_ALM: F1, F2 at the inner solution
+                n_cost++;
+                const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
+                const double ypv = inea ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
+                const double ypw = inea ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+                *LypE = dbl2{ypv, ypw};
+                const double d1 = ypv - yv, d2 = ypw - yw;
+                pk_dy_norm_plus = sqrt(group_sum<PE>(inea ? fma(d1, d1, d2 * d2) : 0.0, lane));
+                pk_f2_norm_plus = sqrt(pen);
+                const double SMALL = DBL_EPSILON;
+                const bool crit1 = nu > 0 && __any(pk_dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
+                const bool crit2 = a.n2 == 0 || __any(pk_f2_norm_plus <= a.op.delta_tolerance + SMALL);
+                const bool crit3 = __any(pk_eps_nu <= a.op.tolerance + SMALL);
+                if (crit1 && crit2 && crit3) {
+                    final_status = inner_status; running = false;
+                } else {
+                    const bool stall = nu == 0 || __any(pk_dy_norm_plus <= a.op.sufficient_decrease * pk_dy_norm + SMALL &&
+                                                        pk_f2_norm_plus <= a.op.sufficient_decrease * pk_f2_norm + SMALL);
+                    if (!stall) { pen_c *= a.op.penalty_update; cbar_inv = 1.0 / fmax(pen_c, 1.0); }
+                    pk_eps_nu = fmax(a.op.tolerance_update * pk_eps_nu, a.op.tolerance);
+                    *Ly = dbl2{ypv, ypw};
+                    pk_dy_norm = pk_dy_norm_plus; pk_f2_norm = pk_f2_norm_plus;
+                    nu++;
+                    if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
+                    else f_start = true;
+                }
+            }
+#ifdef NMPC_PROFILE
+            { double keep = uv + gv + hv + cost; asm volatile("" : "+v"(keep)); }
+            NMPC_TICK(tk1); cyc_post += tk1 - tk0; tk0 = tk1;
+#endif
+        }
+
+        // ------------------------------------------------------------------ results
+        if (in && h == 0) {
+            double *uo = a.u + (size_t)inst * a.n_u;
+            uo[2 * t] = uv; uo[2 * t + 1] = uw;
+            if (a.y_out) { const dbl2 yp_ = *Lyp; a.y_out[(size_t)inst * a.n1 + t] = yp_.x; a.y_out[(size_t)inst * a.n1 + N + t] = yp_.y; }
+        }
+        if (lane == 0 && a.st) {
+            nmpc_status s;
+            s.exit_status = final_status;
+            s.num_outer_iterations = (uint32_t)(final_status == NMPC_NOT_CONVERGED_NOT_FINITE ? nu + 1 : (nu < a.op.max_outer ? nu + 1 : nu));
+            s.num_inner_iterations = inner_total;
+            s.num_cost_evals = n_cost;
+            s.num_grad_evals = n_grad;
+            s.reserved = n_pass;                 // evaluation passes actually executed (diagnostic)
+            s.last_problem_norm_fpr = pk_last_fpr;
+            s.delta_y_norm_over_c = pk_dy_norm_plus / pen_c;
+            s.f2_norm = pk_f2_norm_plus;
+            s.penalty = pen_c;
+            s.cost = pk_last_cost;
+            s.solve_time_ms = 0.0;
+#ifdef NMPC_PROFILE
+            {
+                extern __shared__ long long nmpc_prof_lds[];
+                const long long *e = nmpc_prof_lds + 4096;
+                s.last_problem_norm_fpr = (double)cyc_eval; s.delta_y_norm_over_c = (double)cyc_top; s.f2_norm = (double)cyc_post;
+                s.penalty = (double)e[0]; s.cost = (double)e[1]; s.solve_time_ms = (double)e[2];
+                s.num_cost_evals = (uint32_t)(e[3] / 100); s.num_grad_evals = (uint32_t)(e[4] / 100);
+                s.num_outer_iterations = (uint32_t)(e[5] / 100); s.num_inner_iterations = (uint32_t)(e[6] / 100);
+            }
+#endif
+            a.st[inst] = s;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
+    }
+}
+#undef pk_eps_nu
+#undef pk_dy_norm
+#undef pk_f2_norm
+#undef pk_dy_norm_plus
+#undef pk_f2_norm_plus
+#undef pk_last_fpr
+#undef pk_last_cost
+#undef pk_norm_h
+#undef pk_Lc
+#undef pk_H0
+#undef pk_sigma
+#undef pk_c_lip
+#undef NMPC_FETCH_GRAD
+#undef NMPC_TAKE_TRIAL
+#undef NMPC_HALF_STEP
+#undef NMPC_FBE
+
+}  // namespace nmpc

@@ -123,15 +123,19 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
         s.close()
 
 
-@pytest.mark.parametrize("name,env,kernel", [("cfg1", {}, "nmpc_solve_tri_kernel<ShapeDefault>"),
+@pytest.mark.parametrize("name,env,kernel", [("cfg1", {}, "nmpc_solve_hyb_kernel<ShapeDefault>"),
+                                             ("cfg1", {"NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeDefault>"),
                                              ("cfg1", {"NMPC_LAYOUT": "dual"}, "nmpc_solve_dual_kernel"),
-                                             ("cfg1", {"NMPC_SHAPE": "any"}, "nmpc_solve_tri_kernel<ShapeAny>"),
-                                             ("cfg3", {}, "nmpc_solve_tri_kernel<ShapeNobs50>"),
-                                             ("cfg3", {"NMPC_SHAPE": "any"}, "nmpc_solve_tri_kernel<ShapeAny>"),
+                                             ("cfg1", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
+                                             ("cfg1", {"NMPC_SHAPE": "any", "NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeAny>"),
+                                             ("cfg3", {}, "nmpc_solve_hyb_kernel<ShapeNobs50>"),
+                                             ("cfg3", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
+                                             ("cfg3", {"NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeNobs50>"),
                                              ("cfg2", {}, "nmpc_solve_kernel<64>")])
 def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
-    """Shapes with a specialised three-point kernel: the run-time-shape kernel and the two-point kernel
-    (used for 20 < N_hor <= 32) must give the same bits on them; the handle reports which kernel runs."""
+    """Shapes with a specialised three-point kernel: the run-time-shape kernel, the all-tri-layout kernel
+    and the two-point kernel (used for 20 < N_hor <= 32) must give the same bits on them; the handle
+    reports which kernel runs."""
     from mpc_trajectory_generator_amd.solver import BatchSolver
     cfg = named_config(name)
     P = synthetic_batch(cfg, 11, 40, 4242, synthetic_circles=(name == "cfg3"))
