@@ -66,6 +66,7 @@ struct KArgs {
     nmpc_status *st;
     unsigned int *queue;
     const int *order;          // queue position -> instance (longest-expected-first), or NULL = index order
+    int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
     // eval kernel only
     const double *ev_c;
     const double *ev_y;
@@ -1061,6 +1062,7 @@ static void fill_args(const nmpc_handle *h, KArgs &a, int B)
     a.n_p = nmpc_n_p(&h->pb); a.n_u = nmpc_n_u(&h->pb); a.n1 = nmpc_n1(&h->pb); a.n2 = nmpc_n2(&h->pb);
     a.queue = h->d_queue;
     a.inv_ts = 1.0 / h->pb.ts;
+    if (const char *env = getenv("NMPC_DEBUG_PRIO")) a.dbg = atoi(env);
 }
 
 int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_u, const double *d_y0,

@@ -93,6 +93,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         if (nxt >= (unsigned)a.B) break;
         const int inst = a.order ? a.order[nxt] : (int)nxt;
 
+        const long long dbg_t0 = __builtin_amdgcn_s_memtime();
+        if (a.dbg == 1) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
         DynStage dyn;
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             // Iteration counts are heavy-tailed: an instance that has already run long is likely the
             // one the whole batch will end up waiting for.  Raise its wave's issue priority so that
             // it runs at (nearly) single-wave speed while it still shares its SIMD with another wave.
-            if ((n_pass & 1023u) == 0u) {
+            if (a.dbg == 0 && (n_pass & 1023u) == 0u) {
                 const unsigned lvl = n_pass >> 11;
                 if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
                 else if (lvl == 2u) __builtin_amdgcn_s_setprio(2);
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             s.penalty = pen_c;
             s.cost = pk_last_cost;
             s.solve_time_ms = 0.0;
+            if (a.dbg) s.last_problem_norm_fpr = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
 #ifdef NMPC_PROFILE
             {
                 extern __shared__ long long nmpc_prof_lds[];
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #endif
             a.st[inst] = s;
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
     }
 }
