@@ -22,6 +22,9 @@ ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--scene", type=int, default=11)
 ap.add_argument("--host", action="store_true")
+ap.add_argument("--split", type=int, default=2,
+                help="device loop only: split the fleet into this many sub-fleets, each with its own handle and HIP "
+                     "stream, stepped alternately -- one sub-fleet's slow instances overlap the others' bulk")
 args = ap.parse_args()
 cfg = named_config("cfg4")
 route = harness.scene_route(cfg, args.scene)
@@ -38,18 +41,32 @@ dyn = (c + rng.uniform(-5, 5, (B, K, 2)), c + rng.uniform(-5, 5, (B, K, 2)), rng
 solver = BatchSolver(cfg, max_batch=B)
 if not args.host:
     from mpc_trajectory_generator_amd.trajectory import DeviceRecedingHorizon
-    rh = DeviceRecedingHorizon(solver, route, starts, dyn, max_steps=args.steps, idx0=i0)
-    rh.step()                                   # step 0 = cold start; timed separately
-    st0 = rh.read()[4]                           # (synchronises)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    parts = np.array_split(np.arange(B), args.split)
+    loops, streams = [], []
+    for ids in parts:
+        sv = solver if not loops else BatchSolver(cfg, max_batch=len(ids))
+        loops.append(DeviceRecedingHorizon(sv, route, starts[ids], tuple(a[ids] for a in dyn), max_steps=args.steps, idx0=i0[ids]))
+        strm = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(strm)) == 0
+        streams.append(strm)
+    for rh, strm in zip(loops, streams):
+        rh.step(strm)                           # step 0 = cold start; timed separately
+    st0 = np.concatenate([rh.read()[4] for rh in loops])        # (synchronises)
     t0 = time.perf_counter()
     for k in range(1, args.steps):
-        rh.step()
-    state, last_u, idx, done, st = rh.read()    # synchronises
+        for rh, strm in zip(loops, streams):
+            rh.step(strm)
+    outs = [rh.read() for rh in loops]          # synchronises
     total = time.perf_counter() - t0
+    done = np.concatenate([o[3] for o in outs])
+    st = np.concatenate([o[4] for o in outs])
     print(json.dumps({
         "metric": "nmpc_receding_horizon_solves_per_sec", "value": B * (args.steps - 1) / total, "unit": "solves/s",
         "config": {"workload": f"cfg4 smooth_velocity, scene {args.scene}, B={B}, {args.steps} receding-horizon steps, "
-                               "num_steps_taken=2, warm start (u, y carried; c reset), loop entirely on device",
+                               "num_steps_taken=2, warm start (u, y carried; c reset), loop entirely on device"
+                               + (f", fleet split into {args.split} sub-fleets on {args.split} streams" if args.split > 1 else ""),
                    "kernel": solver.kernel_name},
         "ms_per_step": 1e3 * total / (args.steps - 1), "mean_inner_iters_first_step": float(st0["num_inner_iterations"].mean()),
         "mean_inner_iters_last_step": float(st["num_inner_iterations"].mean()),
