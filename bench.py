@@ -199,7 +199,9 @@ def main():
         # the kernel issues no MFMA -- "bound_detail" says what actually limits it
         "roofline": {"bound": "mfma", "bound_detail": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
-                     "traffic": None, "kernel": solver.kernel_name, "kernel_ms": kern_ms,
+                     "traffic": PMC_TRAFFIC_BYTES.get(args.config) if (B == 8192 and args.routes == 32 and not args.warm) else None,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01)",
+                     "kernel": solver.kernel_name, "kernel_ms": kern_ms,
                      "flops_per_launch": flops,
                      "note": "f64 vector-ALU issue bounds this kernel, not HBM or MFMA (SURVEY.md section 8d); "
                              "MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},
