@@ -1078,8 +1078,8 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     fill_args(h, a, B);
     a.p = d_p; a.u = d_u; a.y0 = d_y0; a.c0 = d_c0; a.y_out = d_y_out; a.st = d_status;
     HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), s));
-    // one instance per wave: N_hor <= 32 runs the dual-evaluation kernel (two query points per
-    // pass), longer horizons the one-point-per-pass kernel with the whole wave as one group
+    // one instance per wave: N_hor <= 20 evaluates three query points per pass (hybrid / tri layouts),
+    // 20 < N_hor <= 32 two (dual kernel), longer horizons one, with the whole wave as one group
     const int grid = B < h->grid_cap ? B : h->grid_cap;
     if (B > grid) {        // more instances than resident waves: hand the hard-looking ones out first
         hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);

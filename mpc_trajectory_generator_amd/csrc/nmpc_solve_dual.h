@@ -1,4 +1,4 @@
-// nmpc_solve_dual.h -- the N_hor <= 32 solver: ONE problem instance per wavefront, the two 32-lane
+// nmpc_solve_dual.h -- the 20 < N_hor <= 32 solver (any N_hor <= 32 with NMPC_LAYOUT=dual): ONE problem instance per wavefront, the two 32-lane
 // halves of the wave evaluate psi at TWO query points per pass.
 //
 // Why: at B = 8192 the batch is bounded by the latency of its slowest instance (thousands of
