@@ -237,7 +237,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int f = 0; f < 5; ++f) cur[j][f] = sg[j * SEG_STRIDE + f];
-#pragma unroll(SH::N > 0 ? 32 : 1)
+#pragma unroll SH::N > 0 ? 32 : 1
         for (int i = 0; i < nseg4; i += 2) {
             sg += 2 * SEG_STRIDE;                           // table is padded: reading one pair past the end is safe
 #pragma unroll
@@ -300,7 +300,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     {
         const lds_double *ob = L + a.map.obs;
         const int nobs4 = (nobs + 3) & ~3;
-#pragma unroll(SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1)
+#pragma unroll SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1
         for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, VALU only
             double od[12];
 #pragma unroll
@@ -1014,9 +1014,9 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_cls, (size_t)max_batch);
     if (e != hipSuccess) { delete h; return NMPC_ERR_HIP; }
     hipDeviceProp_t prop;
-    hipGetDeviceProperties(&prop, device_id);
+    (void)hipGetDeviceProperties(&prop, device_id);
     const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * (64 / h->P);   // eval kernel: one slice per group
-    if (lds_bytes > 160 * 1024) { hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
+    if (lds_bytes > 160 * 1024) { (void)hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
     // the solve kernels use one LDS slice per wave; resident waves per CU are bounded by LDS and by
     // the register budget (2 waves per SIMD)
     int per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
@@ -1034,10 +1034,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
 void nmpc_free(nmpc_handle *h)
 {
     if (!h) return;
-    hipSetDevice(h->device);
-    hipFree(h->d_queue); hipFree(h->d_order); hipFree(h->d_cls);
-    hipFree(h->d_p); hipFree(h->d_u); hipFree(h->d_y0); hipFree(h->d_c0); hipFree(h->d_yout);
-    hipFree(h->d_psi); hipFree(h->d_grad); hipFree(h->d_F1); hipFree(h->d_F2); hipFree(h->d_st);
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->d_queue); (void)hipFree(h->d_order); (void)hipFree(h->d_cls);
+    (void)hipFree(h->d_p); (void)hipFree(h->d_u); (void)hipFree(h->d_y0); (void)hipFree(h->d_c0); (void)hipFree(h->d_yout);
+    (void)hipFree(h->d_psi); (void)hipFree(h->d_grad); (void)hipFree(h->d_F1); (void)hipFree(h->d_F2); (void)hipFree(h->d_st);
     delete h;
 }
 
@@ -1405,7 +1405,7 @@ static int run_unary_test(nmpc_handle *h, int n, const double *x0, const double 
     HIP_TRY(h, hipDeviceSynchronize());
     HIP_TRY(h, hipMemcpy(o0, d[2], (size_t)n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(o1, d[3], (size_t)n * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) hipFree(d[i]);
+    for (int i = 0; i < 4; ++i) (void)hipFree(d[i]);
     return NMPC_OK;
 }
 
