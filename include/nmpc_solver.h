@@ -168,8 +168,10 @@ typedef struct nmpc_route {
 typedef struct nmpc_loop nmpc_loop;
 
 /* starts [B][3] (x, y, theta); idx0 [B] = reference sample each robot starts at, or NULL (0, as
- * the reference).  K <= Ndynobs moving ellipses per robot, dyn [B][K][8] = (p1x, p1y, p2x, p2y,
- * freq, rx, ry, angle) of the reference's linear law (visibility.py:156-166), or NULL with K = 0.
+ * the reference).  K <= Ndynobs moving ellipses per robot, dyn [B][K][10] = (p1x, p1y, p2x, p2y,
+ * freq, rx, ry, angle, sinus, direction): the reference's linear law (visibility.py:156-166), or
+ * with sinus != 0 its sinusoidal law (:177-196, amplitude 1.5; direction = atan2(p2y - p1y,
+ * p2x - p1x), computed by the caller); NULL with K = 0.
  * max_steps > 0 also records the trajectory on device. */
 int nmpc_loop_new(nmpc_handle *h, const nmpc_route *route, int B, const double *starts,
                   const int32_t *idx0, int K, const double *dyn, int max_steps, nmpc_loop **out);

@@ -1251,7 +1251,7 @@ int nmpc_loop_new(nmpc_handle *h, const nmpc_route *r, int B, const double *star
     const size_t n1 = nmpc_n1(&h->pb), ntab = 3 * (size_t)r->n_ref + 2 * (size_t)r->n_vert + 2 * (size_t)r->n_brake;
     const size_t ndynrow = (size_t)a.ndyn * a.N * 5;
     hipError_t e = hipMalloc((void **)&l->d_tab, (ntab ? ntab : 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&l->d_dynpar, ((size_t)B * (K ? K : 1)) * 8 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_dynpar, ((size_t)B * (K ? K : 1)) * 10 * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&l->d_state, (size_t)B * 3 * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&l->d_last_u, (size_t)B * 2 * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&l->d_dyn[0], (size_t)B * (ndynrow ? ndynrow : 1) * 8);
@@ -1278,7 +1278,7 @@ int nmpc_loop_new(nmpc_handle *h, const nmpc_route *r, int B, const double *star
     e = hipMemcpy(l->d_tab, tab.data(), ntab * 8, hipMemcpyHostToDevice);
     a.xr = l->d_tab; a.yr = a.xr + r->n_ref; a.thr = a.yr + r->n_ref; a.vert = a.thr + r->n_ref;
     a.bv = a.vert + 2 * r->n_vert; a.bd = a.bv + r->n_brake;
-    if (e == hipSuccess && K) e = hipMemcpy(l->d_dynpar, dyn, (size_t)B * K * 8 * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && K) e = hipMemcpy(l->d_dynpar, dyn, (size_t)B * K * 10 * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(l->d_state, starts, (size_t)B * 3 * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess && l->d_traj) e = hipMemcpy(l->d_traj, starts, (size_t)B * 3 * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(l->d_last_u, 0, (size_t)B * 2 * 8);

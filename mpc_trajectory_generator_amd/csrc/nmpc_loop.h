@@ -21,7 +21,7 @@ struct LoopArgs {
     double end[3];
     double w[10];
     const double *xr, *yr, *thr, *vert, *bv, *bd;
-    const double *dynpar;     // [B][K][8]: p1x p1y p2x p2y freq rx ry angle
+    const double *dynpar;     // [B][K][10]: p1x p1y p2x p2y freq rx ry angle | sinusoidal law (0 / 1) | atan2(p2 - p1)
     double *state;            // [B][3]
     double *last_u;           // [B][2]
     int *idx;                 // [B]
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void nmpc_loop_assemble_kernel(LoopArgs a)
             double v;
             const bool fresh = k < a.K && (a.t == 0 || st >= N - s);
             if (fresh) {
-                const double *q = a.dynpar + ((size_t)b * a.K + k) * 8;
+                const double *q = a.dynpar + ((size_t)b * a.K + k) * 10;
                 if (f < 2) {
                     const int H = a.t == 0 ? N : s, i = a.t == 0 ? st : st - (N - s);
                     const double t0 = a.t == 0 ? 0.0 : (double)(a.t + N - s) * a.ts;
@@ -111,6 +111,20 @@ __global__ __launch_bounds__(64) void nmpc_loop_assemble_kernel(LoopArgs a)
                     sincos_cw(q[4] * tm, sn, cs);
                     const double w = fabs(sn);
                     v = w * q[f] + (1.0 - w) * q[2 + f];
+                    if (q[8] != 0.0) {
+                        // sinusoidal law (visibility.py:177-196): offset across the p1 -> p2 line, amplitude 1.5
+                        const double p3x = w * q[0] + (1.0 - w) * q[2], p3y = w * q[1] + (1.0 - w) * q[3];
+                        double s10, c10, sa_, ca_;
+                        sincos_cw((10.0 * q[4]) * tm, s10, c10);
+                        sincos_cw(q[9], sa_, ca_);
+                        const double add = 1.5 * c10;
+                        const double dx = p3x - q[0], dy = p3y - q[1];
+                        const double rx = ca_ * dx - sa_ * dy;
+                        double ry = sa_ * dx + ca_ * dy;
+                        ry = ry + add;
+                        const double qx = ca_ * rx - (-sa_) * ry, qy = (-sa_) * rx + ca_ * ry;      // rotate back by -angle
+                        v = f == 0 ? qx + q[0] : qy + q[1];
+                    }
                 } else {
                     v = f == 2 ? q[5] + a.pad : (f == 3 ? q[6] + a.pad : q[7]);
                 }

@@ -205,9 +205,10 @@ class VectorizedRecedingHorizon:
     arrays ``(p1 [B, K, 2], p2 [B, K, 2], freq [B, K], rx [B, K], ry [B, K], angle [B, K])``.
     """
 
-    def __init__(self, route: harness.Route, starts, dyn_obs=None, sincos=None):
+    def __init__(self, route: harness.Route, starts, dyn_obs=None, sincos=None, sinus_object=False):
         cfg = self.cfg = route.cfg
         self.route = route
+        self.sinus_object = bool(sinus_object)     # obstacle index 2 follows the sinusoidal law (visibility.py:183-196,210-212)
         # sin / cos used by the state advance and the obstacle predictor: libm's (as the reference) unless
         # a replacement is given -- the device loop's bit-level mirror passes the kernels' own sin / cos
         self.sincos = sincos if sincos is not None else (lambda x: (np.sin(x), np.cos(x)))
@@ -242,6 +243,20 @@ class VectorizedRecedingHorizon:
         times = np.linspace(t0, t0 + horizon * cfg.ts, horizon)                       # (:204)
         s = np.abs(self.sincos(freq[:, :, None] * times[None, None, :])[0])        # [B, K, H]
         pos = s[..., None] * p1[:, :, None, :] + (1 - s[..., None]) * p2[:, :, None, :]
+        if self.sinus_object and pos.shape[1] > 2:                                   # (:183-196), amplitude 1.5
+            k = 2
+            ang_d = np.arctan2(p2[:, k, 1] - p1[:, k, 1], p2[:, k, 0] - p1[:, k, 0])[:, None]       # [B, 1]
+            add = 1.5 * self.sincos((10 * freq[:, k, None]) * times[None, :])[1]                      # [B, H]
+            sa, ca = self.sincos(ang_d)
+            dx, dy = pos[:, k, :, 0] - p1[:, k, None, 0], pos[:, k, :, 1] - p1[:, k, None, 1]
+            ex = ca * dx - sa * dy
+            ey = sa * dx + ca * dy
+            ey = ey + add
+            sm, cm = self.sincos(-ang_d)
+            qx = cm * (ex - 0.0) - sm * (ey - 0.0)
+            qy = sm * (ex - 0.0) + cm * (ey - 0.0)
+            pos[:, k, :, 0] = qx + p1[:, k, None, 0]
+            pos[:, k, :, 1] = qy + p1[:, k, None, 1]
         pad = cfg.vehicle_width / 2 + cfg.vehicle_margin
         out = np.empty(pos.shape[:3] + (5,))
         out[..., 0:2] = pos
@@ -359,7 +374,8 @@ class DeviceRecedingHorizon:
     reference sample each robot starts at (default 0, as the reference).
     """
 
-    def __init__(self, solver, route: harness.Route, starts, dyn_obs=None, max_steps: int = 0, idx0=None):
+    def __init__(self, solver, route: harness.Route, starts, dyn_obs=None, max_steps: int = 0, idx0=None,
+                 sinus_object=False):
         import ctypes as C
         from . import _lib
         cfg = self.cfg = route.cfg
@@ -372,9 +388,14 @@ class DeviceRecedingHorizon:
         dyn = None
         if K:
             p1, p2, freq, rx, ry, ang = dyn_obs
+            sinus = np.zeros((B, K))
+            if sinus_object and K > 2:
+                sinus[:, 2] = 1.0                  # obstacle index 2 follows the sinusoidal law (visibility.py:210-212)
+            direction = np.arctan2(p2[..., 1] - p1[..., 1], p2[..., 0] - p1[..., 0])
             dyn = np.ascontiguousarray(np.concatenate(
-                [p1, p2, freq[..., None], rx[..., None], ry[..., None], ang[..., None]], axis=2), dtype=np.float64)
-            assert dyn.shape == (B, K, 8)
+                [p1, p2, freq[..., None], rx[..., None], ry[..., None], ang[..., None], sinus[..., None],
+                 direction[..., None]], axis=2), dtype=np.float64)
+            assert dyn.shape == (B, K, 10)
         r = _lib.NmpcRoute()
         keep = []                                              # arrays the struct points to, until nmpc_loop_new returns
 

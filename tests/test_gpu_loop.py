@@ -28,8 +28,9 @@ def _fleet(cfg, route, B, seed, K):
     return i0, starts, dyn
 
 
-@pytest.mark.parametrize("name,scene,K,steps", [("cfg4", 11, 3, 12), ("cfg4", 1, 2, 40), ("cfg1", 11, 0, 8), ("nobs3", 11, 1, 6)])
-def test_device_loop_equals_host_mirror(name, scene, K, steps):
+@pytest.mark.parametrize("name,scene,K,steps,sinus", [("cfg4", 11, 3, 12, False), ("cfg4", 1, 2, 40, False), ("cfg1", 11, 0, 8, False),
+                                                       ("nobs3", 11, 1, 6, False), ("cfg4", 11, 3, 10, True)])
+def test_device_loop_equals_host_mirror(name, scene, K, steps, sinus):
     from mpc_trajectory_generator_amd.solver import BatchSolver
     from mpc_trajectory_generator_amd.trajectory import DeviceRecedingHorizon, VectorizedRecedingHorizon
     # "nobs3": fewer circle slots than the scene has vertices -> the closest-vertex window is exercised
@@ -40,8 +41,8 @@ def test_device_loop_equals_host_mirror(name, scene, K, steps):
     o = oracle_for(cfg)
     s = BatchSolver(cfg, max_batch=32)
     try:
-        dev = DeviceRecedingHorizon(s, route, starts, dyn, max_steps=steps, idx0=i0)
-        host = VectorizedRecedingHorizon(route, starts, dyn, sincos=o.sincos_array)
+        dev = DeviceRecedingHorizon(s, route, starts, dyn, max_steps=steps, idx0=i0, sinus_object=sinus)
+        host = VectorizedRecedingHorizon(route, starts, dyn, sincos=o.sincos_array, sinus_object=sinus)   # (third ellipse: sinusoidal law)
         host.idx = i0.astype(np.int64)
         for k in range(steps):
             dev.step()

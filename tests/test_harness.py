@@ -146,9 +146,10 @@ def test_synthetic_batch_is_deterministic_and_well_formed():
     assert C.shape == (8, 550) and np.all(C[:, 40:190].reshape(8, 50, 3)[:, :, 2] == 0.5)
 
 
-def test_vectorized_receding_horizon_equals_loop_version():
+@pytest.mark.parametrize("sinus", [False, True])
+def test_vectorized_receding_horizon_equals_loop_version(sinus):
     """NumPy-vectorised batch assembly == the per-robot loops, bit for bit, incl. per-robot dynamic
-    obstacles, num_steps_taken = 2 and the braking zone."""
+    obstacles (linear and sinusoidal law), num_steps_taken = 2 and the braking zone."""
     from conftest import oracle_for
     from mpc_trajectory_generator_amd.trajectory import VectorizedRecedingHorizon
     cfg = named_config("cfg4")
@@ -162,13 +163,13 @@ def test_vectorized_receding_horizon_equals_loop_version():
         lists.append([[list(rng.uniform(0, 20, 2)), list(rng.uniform(0, 20, 2)), rng.uniform(0.05, 0.1),
                        rng.uniform(0.3, 1), rng.uniform(0.3, 1), rng.uniform(0, 3)] for _ in range(3)])
     B = len(starts)
-    loop = BatchedRecedingHorizon(route, starts, lists)
+    loop = BatchedRecedingHorizon(route, starts, lists, sinus_object=sinus)
     for b in range(B):                                              # start the window search where the robot is
         loop.idx[b] = [0, 3, n - 25, n - 8, n - 2, 40][b]
     arr = lambda f: np.array([[f(o_) for o_ in l] for l in lists])  # noqa: E731
     dyn = (arr(lambda o_: o_[0]), arr(lambda o_: o_[1]), arr(lambda o_: o_[2]), arr(lambda o_: o_[3]),
            arr(lambda o_: o_[4]), arr(lambda o_: o_[5]))
-    vec = VectorizedRecedingHorizon(route, starts, dyn)
+    vec = VectorizedRecedingHorizon(route, starts, dyn, sinus_object=sinus)
     vec.idx = np.array(loop.idx)
     solve = lambda P, U, Y: o.solve_batch(P, u0=U, y0=Y, threads=4)         # noqa: E731
     for k in range(6):
