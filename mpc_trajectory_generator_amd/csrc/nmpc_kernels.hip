@@ -1012,11 +1012,11 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_queue, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_order, sizeof(int) * (size_t)max_batch);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_cls, (size_t)max_batch);
-    if (e != hipSuccess) { delete h; return NMPC_ERR_HIP; }
+    if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, device_id);
     const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * (64 / h->P);   // eval kernel: one slice per group
-    if (lds_bytes > 160 * 1024) { (void)hipFree(h->d_queue); delete h; return NMPC_ERR_BAD_PROBLEM; }
+    if (lds_bytes > 160 * 1024) { nmpc_free(h); return NMPC_ERR_BAD_PROBLEM; }
     // the solve kernels use one LDS slice per wave; resident waves per CU are bounded by LDS and by
     // the register budget (2 waves per SIMD)
     int per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
@@ -1395,18 +1395,21 @@ static int run_unary_test(nmpc_handle *h, int n, const double *x0, const double 
     if (n == 0) return NMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     double *d[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 4; ++i) HIP_TRY(h, hipMalloc((void **)&d[i], (size_t)n * 8));
-    HIP_TRY(h, hipMemcpy(d[0], x0, (size_t)n * 8, hipMemcpyHostToDevice));
-    if (x1) HIP_TRY(h, hipMemcpy(d[1], x1, (size_t)n * 8, hipMemcpyHostToDevice));
-    const int blocks = (n + 255) / 256;
-    if (which == 0) hipLaunchKernelGGL(nmpc_test_sincos_kernel, dim3(blocks), dim3(256), 0, nullptr, n, d[0], d[2], d[3]);
-    else hipLaunchKernelGGL(nmpc_test_divsqrt_kernel, dim3(blocks), dim3(256), 0, nullptr, n, d[0], d[1], d[2], d[3]);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(o0, d[2], (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(o1, d[3], (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipMalloc((void **)&d[i], (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d[0], x0, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && x1) e = hipMemcpy(d[1], x1, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int blocks = (n + 255) / 256;
+        if (which == 0) hipLaunchKernelGGL(nmpc_test_sincos_kernel, dim3(blocks), dim3(256), 0, nullptr, n, d[0], d[2], d[3]);
+        else hipLaunchKernelGGL(nmpc_test_divsqrt_kernel, dim3(blocks), dim3(256), 0, nullptr, n, d[0], d[1], d[2], d[3]);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(o0, d[2], (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(o1, d[3], (size_t)n * 8, hipMemcpyDeviceToHost);
     for (int i = 0; i < 4; ++i) (void)hipFree(d[i]);
-    return NMPC_OK;
+    return e == hipSuccess ? NMPC_OK : fail(h, NMPC_ERR_HIP, "arithmetic primitive test", e);
 }
 
 int nmpc_test_sincos_host(nmpc_handle *h, int n, const double *x, double *out_s, double *out_c)
