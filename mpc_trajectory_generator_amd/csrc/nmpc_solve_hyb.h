@@ -94,7 +94,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         const int inst = a.order ? a.order[nxt] : (int)nxt;
 
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
-        if (a.dbg == 1) { if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+        // experiments: the wave slot within the SIMD (HW_ID[3:0]) decides the priority, so the two waves of a SIMD differ
+        const unsigned hw_slot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4);
+        if (a.dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
         DynStage dyn;
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
@@ -483,7 +485,11 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             s.penalty = pen_c;
             s.cost = pk_last_cost;
             s.solve_time_ms = 0.0;
-            if (a.dbg) s.last_problem_norm_fpr = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
+            if (a.dbg) {       // cycles spent on this instance, wave slot, finish time on the 100 MHz reference clock
+                s.last_problem_norm_fpr = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
+                s.f2_norm = (double)hw_slot;
+                s.cost = (double)__builtin_amdgcn_s_memrealtime();
+            }
 #ifdef NMPC_PROFILE
             {
                 extern __shared__ long long nmpc_prof_lds[];

@@ -1,6 +1,6 @@
 """Does s_setprio let one wave of a SIMD run at lone speed?  2048 copies of one hard instance (every wave slot
-busy with identical work); NMPC_DEBUG_PRIO=1 gives even workgroups priority 3 and odd ones 0, =2 leaves
-all at 0.  Prints the per-wave cycle counts by parity."""
+busy with identical work); NMPC_DEBUG_PRIO=1 gives the waves in even hardware slots priority 3 and those in odd slots 0, =2 leaves
+all at 0.  Prints the per-wave cycle counts by slot parity."""
 import os
 import sys
 import numpy as np
@@ -17,6 +17,9 @@ for B in (1, 1024, 2048):
     sol.solve(Pb)
     _, _, s = sol.solve(Pb)
     c = s["last_problem_norm_fpr"]
-    ev, od = c[0::2], c[1::2]
-    print(f"dbg={os.environ.get('NMPC_DEBUG_PRIO')} B={B}: kernel {s['solve_time_ms'][0]:.1f} ms; cycles/1e6 even: mean {ev.mean()/1e6:.1f} min {ev.min()/1e6:.1f} max {ev.max()/1e6:.1f}"
+    slot = s["f2_norm"].astype(int)                      # hardware wave slot within the SIMD (debug fields of the status)
+    ev, od = c[slot % 2 == 0], c[slot % 2 == 1]
+    print("  wave slots used:", np.bincount(slot))
+    print(f"dbg={os.environ.get('NMPC_DEBUG_PRIO')} B={B}: kernel {s['solve_time_ms'][0]:.1f} ms, {s['reserved'][0]} passes, "
+          f"{1e3 * s['solve_time_ms'][0] / s['reserved'][0]:.2f} us/pass; cycles/1e6 even: mean {ev.mean()/1e6:.1f} min {ev.min()/1e6:.1f} max {ev.max()/1e6:.1f}"
           + (f" | odd: mean {od.mean()/1e6:.1f} min {od.min()/1e6:.1f} max {od.max()/1e6:.1f}" if len(od) else ""))

@@ -1,0 +1,25 @@
+"""Headline batch with NMPC_DEBUG_PRIO=2: which hardware wave slot each instance ran on, how fast, and when it
+finished (the status fields last_problem_norm_fpr / f2_norm / cost carry cycles / slot / 100 MHz finish time)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, ".")
+from mpc_trajectory_generator_amd import named_config
+from mpc_trajectory_generator_amd.solver import BatchSolver
+from mpc_trajectory_generator_amd.harness import synthetic_batch
+from mpc_trajectory_generator_amd.frontend import random_routes
+cfg = named_config("cfg1")
+sol = BatchSolver(cfg, max_batch=8192)
+P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=1000))
+sol.solve(P)
+u, y, st = sol.solve(P)
+ps = st["reserved"].astype(np.int64); cyc = st["last_problem_norm_fpr"]; slot = st["f2_norm"].astype(int)
+print("kernel ms", st["solve_time_ms"][0], "slots", np.bincount(slot))
+end = (st["cost"] - st["cost"].min()) / 100e3          # ms since the first instance finished (100 MHz clock)
+last = np.argsort(-end)[:10]
+print("  last to finish:", [(int(b), int(ps[b]), int(slot[b]), round(float(end[b]), 1)) for b in last], "(inst, passes, slot, ms)")
+top = np.argsort(-ps)[:12]
+for b in top:
+    print(f"  inst {b}: passes {ps[b]} slot {slot[b]} {cyc[b]/2.4e3/ps[b]:.2f} us/pass, finished at {end[b]:.1f} ms")
+for s_ in (0, 1):
+    m = (slot == s_) & (ps > 3000)
+    print(f"  slot {s_}: instances>3000 passes: {m.sum()}, mean us/pass {np.mean(cyc[m]/2.4e3/ps[m]):.2f}")
