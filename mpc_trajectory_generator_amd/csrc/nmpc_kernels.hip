@@ -103,6 +103,7 @@ struct DynStage {
 struct ShapeAny { static constexpr int N = 0, NOBS = -1, NDYN = -1; };
 struct ShapeDefault { static constexpr int N = 20, NOBS = 10, NDYN = 3; };
 struct ShapeNobs50 { static constexpr int N = 20, NOBS = 50, NDYN = 3; };     // BASELINE config 3
+struct ShapeN40 { static constexpr int N = 40, NOBS = 10, NDYN = 3; };        // BASELINE config 2
 template <class SH> __device__ __forceinline__ int shape_N(const KArgs &a) { if constexpr (SH::N > 0) return SH::N; else return a.pb.N; }
 template <class SH> __device__ __forceinline__ int shape_nobs(const KArgs &a) { if constexpr (SH::NOBS >= 0) return SH::NOBS; else return a.pb.nobs; }
 template <class SH> __device__ __forceinline__ int shape_ndyn(const KArgs &a) { if constexpr (SH::NDYN >= 0) return SH::NDYN; else return a.pb.ndyn; }
@@ -237,7 +238,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int f = 0; f < 5; ++f) cur[j][f] = sg[j * SEG_STRIDE + f];
-#pragma unroll SH::N > 0 ? 32 : 1
+#pragma unroll SH::N > 0 ? (SH::N <= 20 ? 32 : 2) : 1
         for (int i = 0; i < nseg4; i += 2) {
             sg += 2 * SEG_STRIDE;                           // table is padded: reading one pair past the end is safe
 #pragma unroll
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
 // ---------------------------------------------------------------------------------------------
 enum : int { ST_IDLE = 0, ST_INIT0, ST_INIT1, ST_LIP, ST_FB0, ST_LS, ST_ALM };
 
-template <int P>
+template <int P, class SH = ShapeAny>
 __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 {
     extern __shared__ double lds[];
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 done = true;
             } else {
                 inst = a.order ? a.order[nxt] : (int)nxt;
-                prepare_instance<P>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+                prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
                 const double *u0 = a.u + (size_t)inst * a.n_u;
                 uv = in ? u0[2 * t] : 0.0;
                 uw = in ? u0[2 * t + 1] : 0.0;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
         // ------------------------------------------------------------------ one evaluation of psi per group
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         const bool wg = __any(live && need_grad);
-        eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
+        eval_psi<P, SH>(a, L, a.map.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
         if (!live) continue;
 
         // ------------------------------------------------------------------ consume it
@@ -903,6 +904,7 @@ struct nmpc_handle {
     int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one)
     bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
     bool shape_nobs50;     // ... == ShapeNobs50
+    bool shape_n40;        // ... == ShapeN40
     bool hybrid;           // P == 20: solver state in the two-half layout, evaluation in the tri layout (nmpc_solve_hyb.h)
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
@@ -999,8 +1001,9 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
     h->shape_nobs50 = pb->N == nmpc::ShapeNobs50::N && pb->nobs == nmpc::ShapeNobs50::NOBS &&
                       pb->ndyn == nmpc::ShapeNobs50::NDYN;
+    h->shape_n40 = pb->N == nmpc::ShapeN40::N && pb->nobs == nmpc::ShapeN40::NOBS && pb->ndyn == nmpc::ShapeN40::NDYN;
     if (const char *env = getenv("NMPC_SHAPE")) {              // experiments: force the run-time-shape kernel
-        if (!strcmp(env, "any")) h->shape_default = h->shape_nobs50 = false;
+        if (!strcmp(env, "any")) h->shape_default = h->shape_nobs50 = h->shape_n40 = false;
     }
     h->map = make_map(*pb, op.lbfgs_memory, h->P);
     h->d_queue = nullptr;
@@ -1052,7 +1055,7 @@ const char *nmpc_kernel_name(const nmpc_handle *h)
     if (h->P == 20)
         return h->shape_default ? "nmpc_solve_tri_kernel<ShapeDefault>"
                                 : (h->shape_nobs50 ? "nmpc_solve_tri_kernel<ShapeNobs50>" : "nmpc_solve_tri_kernel<ShapeAny>");
-    return h->P == 32 ? "nmpc_solve_dual_kernel" : "nmpc_solve_kernel<64>";
+    return h->P == 32 ? "nmpc_solve_dual_kernel" : (h->shape_n40 ? "nmpc_solve_kernel<64, ShapeN40>" : "nmpc_solve_kernel<64>");
 }
 
 static void fill_args(const nmpc_handle *h, KArgs &a, int B)
@@ -1098,6 +1101,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     else if (h->P == 20 && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
+    else if (h->shape_n40) hipLaunchKernelGGL((nmpc::nmpc_solve_kernel<64, nmpc::ShapeN40>), dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;

@@ -131,7 +131,8 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
                                              ("cfg3", {}, "nmpc_solve_hyb_kernel<ShapeNobs50>"),
                                              ("cfg3", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
                                              ("cfg3", {"NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeNobs50>"),
-                                             ("cfg2", {}, "nmpc_solve_kernel<64>")])
+                                             ("cfg2", {}, "nmpc_solve_kernel<64, ShapeN40>"),
+                                             ("cfg2", {"NMPC_SHAPE": "any"}, "nmpc_solve_kernel<64>")])
 def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
     """Shapes with a specialised three-point kernel: the run-time-shape kernel, the all-tri-layout kernel
     and the two-point kernel (used for 20 < N_hor <= 32) must give the same bits on them; the handle
