@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
             "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
             "wait:SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"; do
