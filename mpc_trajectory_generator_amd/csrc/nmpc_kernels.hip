@@ -825,6 +825,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 namespace nmpc {
 constexpr double SCHED_CLEARANCE = 0.6;    // m
 constexpr double SCHED_BEND = 0.05;        // rad, summed |heading change| of the reference samples
+constexpr double SCHED_SPEED_GAP = 1.0;    // m/s between the last applied and the first reference speed: the
+                                           // acceleration bounds stay active for several stages (many outer iterations)
+constexpr int SCHED_LEVELS = 5;            // hardness level = number of criteria met, 0..4
 
 __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
 {
@@ -855,35 +858,48 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
             hard |= dx * dx + dy * dy < lim * lim;
         }
     }
-    cls[b] = (unsigned char)((hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0));      // 2: both, 1: one of them, 0: neither
+    const bool gap = fabs(p[NZ] - p[3]) > SCHED_SPEED_GAP;
+    // the horizon reaches the goal: the reference is padded with the end pose (degenerate segments, braking profile)
+    const bool goal = pr[3 * (N - 1)] == pr[3 * (N - 2)] && pr[3 * (N - 1) + 1] == pr[3 * (N - 2) + 1];
+    cls[b] = (unsigned char)((hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0) + (gap ? 1 : 0) + (goal ? 1 : 0));    // criteria met
 }
 
-// stable three-way partition of 0..B-1 by class (2, then 1, then 0); one block, deterministic
+// stable partition of 0..B-1 by level (highest first); one block, deterministic
 __global__ void nmpc_order_kernel(int B, const unsigned char *cls, int *order)
 {
-    __shared__ int cnt2[1024], cnt1[1024];
+    __shared__ int cnt[SCHED_LEVELS][1024];
     const int t = threadIdx.x, nt = blockDim.x;
     const int chunk = (B + nt - 1) / nt;
     const int lo = t * chunk < B ? t * chunk : B, hi = lo + chunk < B ? lo + chunk : B;
-    int c2 = 0, c1 = 0;
-    for (int i = lo; i < hi; ++i) { c2 += cls[i] == 2; c1 += cls[i] == 1; }
-    cnt2[t] = c2;
-    cnt1[t] = c1;
+    int c[SCHED_LEVELS];
+#pragma unroll
+    for (int k = 0; k < SCHED_LEVELS; ++k) c[k] = 0;
+    for (int i = lo; i < hi; ++i) {
+#pragma unroll
+        for (int k = 0; k < SCHED_LEVELS; ++k) c[k] += cls[i] == k;
+    }
+#pragma unroll
+    for (int k = 0; k < SCHED_LEVELS; ++k) cnt[k][t] = c[k];
     __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {            // inclusive scans
-        const int v2 = t >= off ? cnt2[t - off] : 0, v1 = t >= off ? cnt1[t - off] : 0;
+    for (int off = 1; off < nt; off <<= 1) {            // inclusive scans, one per level
+        int v[SCHED_LEVELS];
+#pragma unroll
+        for (int k = 0; k < SCHED_LEVELS; ++k) v[k] = t >= off ? cnt[k][t - off] : 0;
         __syncthreads();
-        cnt2[t] += v2;
-        cnt1[t] += v1;
+#pragma unroll
+        for (int k = 0; k < SCHED_LEVELS; ++k) cnt[k][t] += v[k];
         __syncthreads();
     }
-    const int total2 = cnt2[nt - 1], total1 = cnt1[nt - 1];
-    int p2 = cnt2[t] - c2;                               // class-2 instances before this chunk
-    int p1 = total2 + (cnt1[t] - c1);                    // class-1 instances go after all of class 2
-    int p0 = total2 + total1 + (lo - (cnt2[t] - c2) - (cnt1[t] - c1));
+    int pos[SCHED_LEVELS], base = 0;                    // write cursor of this chunk inside each level's segment
+#pragma unroll
+    for (int k = SCHED_LEVELS - 1; k >= 0; --k) {
+        pos[k] = base + cnt[k][t] - c[k];
+        base += cnt[k][nt - 1];
+    }
     for (int i = lo; i < hi; ++i) {
-        const int c = cls[i];
-        if (c == 2) order[p2++] = i; else if (c == 1) order[p1++] = i; else order[p0++] = i;
+        const int k = cls[i];
+#pragma unroll
+        for (int j = 0; j < SCHED_LEVELS; ++j) if (k == j) order[pos[j]++] = i;
     }
 }
 }  // namespace nmpc
