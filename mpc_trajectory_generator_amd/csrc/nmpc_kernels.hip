@@ -66,6 +66,12 @@ struct KArgs {
     nmpc_status *st;
     unsigned int *queue;
     const int *order;          // queue position -> instance (longest-expected-first), or NULL = index order
+    // migration of long-running instances to the SIMD's favoured wave slot (nmpc_solve_hyb.h), 0 = off
+    int park_min;              // passes after which an instance on an unfavoured wave is parked at an outer-iteration boundary
+    int park_depth;            // ... unless this many parked instances are already waiting for a favoured wave
+    double *park;              // [B][park_stride]: parked solver state
+    int *pool;                 // [B]: parked instance ids in arrival order (-1: not yet published)
+    unsigned int *pool_ctr;    // [0] next index to pop, [1] next index to push
     int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
     // eval kernel only
     const double *ev_c;
@@ -810,6 +816,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
 
 }  // namespace nmpc
 
+namespace nmpc {
+// doubles per parked instance: u, y, previous gradient (2N each) + 16 scalars
+__host__ __device__ inline int park_stride(int N) { return 6 * N + 16; }
+}
 #include "nmpc_solve_dual.h"
 #include "nmpc_solve_tri.h"
 #include "nmpc_solve_hyb.h"
@@ -924,6 +934,10 @@ struct nmpc_handle {
     bool hybrid;           // P == 20: solver state in the two-half layout, evaluation in the tri layout (nmpc_solve_hyb.h)
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
+    int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
+    double *d_park;            // parked solver states, allocated on first use
+    int *d_pool;
+    unsigned int *d_pool_ctr;
     int *d_order;              // launch order (hard-looking instances first)
     unsigned char *d_cls;
     // staging buffers of the host path
@@ -1023,6 +1037,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     }
     h->map = make_map(*pb, op.lbfgs_memory, h->P);
     h->d_queue = nullptr;
+    h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
+    h->park_min = 500; h->park_depth = 8;
+    if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // tuning knobs; 0 switches migration off
+    if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
     h->d_order = nullptr;
     h->d_cls = nullptr;
     h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
@@ -1055,6 +1073,7 @@ void nmpc_free(nmpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_queue); (void)hipFree(h->d_order); (void)hipFree(h->d_cls);
+    (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr);
     (void)hipFree(h->d_p); (void)hipFree(h->d_u); (void)hipFree(h->d_y0); (void)hipFree(h->d_c0); (void)hipFree(h->d_yout);
     (void)hipFree(h->d_psi); (void)hipFree(h->d_grad); (void)hipFree(h->d_F1); (void)hipFree(h->d_F2); (void)hipFree(h->d_st);
     delete h;
@@ -1104,6 +1123,17 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
         hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
         a.order = h->d_order;
+        if (h->P == 20 && h->hybrid && h->park_min > 0) {      // two waves per SIMD: long-runners migrate to the favoured one
+            if (!h->d_park) {
+                HIP_TRY(h, hipMalloc((void **)&h->d_park, (size_t)h->max_batch * nmpc::park_stride(h->pb.N) * 8));
+                HIP_TRY(h, hipMalloc((void **)&h->d_pool, (size_t)h->max_batch * sizeof(int)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_pool_ctr, 2 * sizeof(unsigned int)));
+            }
+            HIP_TRY(h, hipMemsetAsync(h->d_pool, 0xFF, (size_t)B * sizeof(int), s));
+            HIP_TRY(h, hipMemsetAsync(h->d_pool_ctr, 0, 2 * sizeof(unsigned int), s));
+            a.park_min = h->park_min; a.park_depth = h->park_depth;
+            a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr;
+        }
     }
 #ifdef NMPC_PROFILE
     const size_t lds = 4096 * 8 + 256;

@@ -15,6 +15,14 @@
 // Trials are consumed in order and the first accepted one ends the iteration, exactly as the
 // sequential line search would; evaluations past the accepted trial are discarded and not counted.
 // Same results and counters as nmpc_solve_tri.h, nmpc_solve_dual.h and the sequential oracle.
+//
+// Migration.  With two waves resident per SIMD the hardware serves the older wave slot first: measured on
+// MI355X (scripts/slot_probe.py) a pass costs 5.3 us on wave slot 0 and 6.2-7.1 us on slot 1, whatever
+// s_setprio says, and a batch ends when its slowest instance does.  So an instance that has already run
+// `park_min` passes on an unfavoured wave is PARKED at its next outer-iteration boundary (the state there is
+// small: u, y, the previous gradient and a dozen scalars) and pushed to a pool; favoured waves look into the
+// pool before they take new work from the queue and resume it.  The arithmetic does not change, only where
+// an instance runs; the pusher itself falls back to the pool once the queue is exhausted, so nothing is lost.
 #pragma once
 
 namespace nmpc {
@@ -35,6 +43,29 @@ namespace nmpc {
     } while (0)
 // FBE at the cached point; the gradient step x - gamma g is recomputed (bitwise the same value)
 #define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
+
+// parked-instance pool: one lane calls these.  Entries are published with release semantics at agent scope and
+// read with acquire semantics (other XCDs' L2s are not coherent with ours: plain loads could see stale lines)
+__device__ __forceinline__ int pool_pop(const KArgs &a)
+{
+    for (;;) {
+        const unsigned hd = __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tl = __hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hd >= tl) return -1;
+        unsigned expect = hd;
+        if (__hip_atomic_compare_exchange_strong(&a.pool_ctr[0], &expect, hd + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+            int inst;
+            do { inst = __hip_atomic_load(&a.pool[hd], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (inst < 0);
+            return inst;
+        }
+    }
+}
+__device__ __forceinline__ void pool_push(const KArgs &a, int inst)
+{
+    const unsigned slot = __hip_atomic_fetch_add(&a.pool_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.pool[slot], inst, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // publishes the parked state too
+}
 
 template <class SH>
 __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
@@ -85,17 +116,28 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
 
+    // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
+    const unsigned hw_slot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4);
+    const bool unfavoured = hw_slot != 0u;
+    const int PS = park_stride(N);
+
     for (;;) {
-        // ------------------------------------------------------------------ next instance from the queue
-        unsigned nxt = 0;
-        if (lane == 0) nxt = atomicAdd(a.queue, 1u);
-        nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
-        if (nxt >= (unsigned)a.B) break;
-        const int inst = a.order ? a.order[nxt] : (int)nxt;
+        // ------------------------------------------------------------------ next instance: parked long-runners first
+        // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
+        int fetched = -1, from_pool = 0;
+        if (lane == 0) {
+            if (a.park_min > 0 && !unfavoured) { fetched = pool_pop(a); from_pool = fetched >= 0; }
+            if (fetched < 0) {
+                const unsigned nxt = atomicAdd(a.queue, 1u);
+                if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
+                else if (a.park_min > 0) { fetched = pool_pop(a); from_pool = fetched >= 0; }
+            }
+        }
+        const int inst = __builtin_amdgcn_readfirstlane(fetched);
+        const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
+        if (inst < 0) break;
 
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
-        // experiments: the wave slot within the SIMD (HW_ID[3:0]) decides the priority, so the two waves of a SIMD differ
-        const unsigned hw_slot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4);
         if (a.dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
         DynStage dyn;
@@ -103,15 +145,24 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         *Lvr = vref_;
 
         // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
-        const double *u0 = a.u + (size_t)inst * a.n_u;
+        // a fresh instance starts from the caller's u0 / y0; a resumed one from its parked state (acquired by pool_pop)
+        const double *pk = a.park + (size_t)inst * PS;
+        const double *u0 = resumed ? pk : a.u + (size_t)inst * a.n_u;
         double uv = in ? u0[2 * t] : 0.0, uw = in ? u0[2 * t + 1] : 0.0;
         {
-            const double yv0 = (a.y0 && ine) ? a.y0[(size_t)inst * a.n1 + te] : 0.0;
-            const double yw0 = (a.y0 && ine) ? a.y0[(size_t)inst * a.n1 + N + te] : 0.0;
+            double yv0, yw0;
+            if (resumed) {
+                yv0 = ine ? pk[2 * N + 2 * te] : 0.0;
+                yw0 = ine ? pk[2 * N + 2 * te + 1] : 0.0;
+            } else {
+                yv0 = (a.y0 && ine) ? a.y0[(size_t)inst * a.n1 + te] : 0.0;
+                yw0 = (a.y0 && ine) ? a.y0[(size_t)inst * a.n1 + N + te] : 0.0;
+            }
             *LypE = dbl2{yv0, yw0};
             *Ly = dbl2{yv0, yw0};
         }
-        *Lq = dbl2{0.0, 0.0};                    // gradient_u_previous (AKKT residual) starts at zero
+        // gradient_u_previous (AKKT residual): zero at the start of a solve, carried across its inner solves
+        *Lq = (resumed && in) ? dbl2{pk[4 * N + 2 * t], pk[4 * N + 2 * t + 1]} : dbl2{0.0, 0.0};
         double gv = 0, gw = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
         double pv = 0, pw = 0;                    // line-search trial point being consumed
         double xv = 0, xw = 0;                    // query point X of THIS half (-> evaluation points 0 and 1)
@@ -128,16 +179,21 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         bool n_first = true, n_take_old = false;
         double n_H0 = 1;
         unsigned num_iter = 0;
+        const double *pks = pk + 6 * N;           // parked scalars
         const double c0 = a.c0 ? a.c0[inst] : 0.0;
-        double pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
+        double pen_c = resumed ? pks[0] : (c0 > 0.0 ? c0 : a.op.initial_penalty);
         double cbar_inv = 1.0 / fmax(pen_c, 1.0);          // 1 / max(c, 1), refreshed when c changes
         pk_c_lip = 0.0;                                     // 0.95 / (2 gamma), refreshed when gamma changes
         // scalars touched once per inner solve / outer iteration are parked in LDS (every lane writes the
         // same value) instead of occupying a VGPR pair each for the whole solve
-        pk_eps_nu = a.op.initial_tolerance;
-        pk_dy_norm = 0.0; pk_f2_norm = 0.0; pk_dy_norm_plus = DBL_MAX; pk_f2_norm_plus = 0.0; pk_last_fpr = 0.0; pk_last_cost = 0.0; pk_norm_h = 0.0;
-        int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
-        unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
+        pk_eps_nu = resumed ? pks[1] : a.op.initial_tolerance;
+        pk_dy_norm = resumed ? pks[2] : 0.0; pk_f2_norm = resumed ? pks[3] : 0.0;
+        pk_dy_norm_plus = resumed ? pks[4] : DBL_MAX; pk_f2_norm_plus = resumed ? pks[5] : 0.0;
+        pk_last_fpr = resumed ? pks[6] : 0.0; pk_last_cost = resumed ? pks[7] : 0.0; pk_norm_h = 0.0;
+        int nu = resumed ? (int)pks[8] : 0, inner_status = 0, state = D_INIT, final_status = 0;
+        unsigned inner_total = resumed ? (unsigned)pks[9] : 0u, n_cost = resumed ? (unsigned)pks[10] : 0u;
+        unsigned n_grad = resumed ? (unsigned)pks[11] : 0u, n_pass = resumed ? (unsigned)pks[12] : 0u;
+        bool parked = false;
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
@@ -456,7 +512,14 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                     pk_dy_norm = pk_dy_norm_plus; pk_f2_norm = pk_f2_norm_plus;
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
-                    else f_start = true;
+                    else if (a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min &&
+                             __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.B &&
+                             __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                                                  __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) < a.park_depth) {
+                        // a long-runner on the unfavoured wave slot, favoured waves will still come back for work
+                        // and few instances are waiting for them already: hand it over at this outer-iteration boundary
+                        parked = true; running = false;
+                    } else f_start = true;
                 }
             }
 #ifdef NMPC_PROFILE
@@ -465,6 +528,28 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #endif
         }
 
+        // ------------------------------------------------------------------ parked: state out, into the pool
+        if (parked) {
+            double *po = a.park + (size_t)inst * PS;
+            if (in && h == 0) {
+                po[2 * t] = uv; po[2 * t + 1] = uw;
+                const dbl2 q_ = *Lq;
+                po[4 * N + 2 * t] = q_.x; po[4 * N + 2 * t + 1] = q_.y;
+            }
+            if (ine && q == 0) { const dbl2 y_ = *Ly; po[2 * N + 2 * te] = y_.x; po[2 * N + 2 * te + 1] = y_.y; }
+            if (lane == 0) {
+                double *ps_ = po + 6 * N;
+                ps_[0] = pen_c; ps_[1] = pk_eps_nu; ps_[2] = pk_dy_norm; ps_[3] = pk_f2_norm; ps_[4] = pk_dy_norm_plus;
+                ps_[5] = pk_f2_norm_plus; ps_[6] = pk_last_fpr; ps_[7] = pk_last_cost; ps_[8] = (double)nu;
+                ps_[9] = (double)inner_total; ps_[10] = (double)n_cost; ps_[11] = (double)n_grad; ps_[12] = (double)n_pass;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) pool_push(a, inst);
+            if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
+            NMPC_WAVE_SYNC();
+            continue;
+        }
         // ------------------------------------------------------------------ results
         if (in && h == 0) {
             double *uo = a.u + (size_t)inst * a.n_u;

@@ -150,6 +150,31 @@ def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
         s.close()
 
 
+def test_migration_between_wave_slots_is_invisible(monkeypatch):
+    """More instances than resident waves: long-running instances on the unfavoured wave slot of a SIMD are
+    parked at outer-iteration boundaries and resumed by favoured waves (nmpc_solve_hyb.h).  With an aggressive
+    threshold nearly every multi-outer-iteration instance migrates, some several times; results and counters
+    must still be those of the sequential oracle."""
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = named_config("cfg1")
+    P = synthetic_batch(cfg, 11, 2600, 99)
+    monkeypatch.setenv("NMPC_PARK_MIN", "20")
+    monkeypatch.setenv("NMPC_PARK_DEPTH", "64")
+    s = BatchSolver(cfg, max_batch=2600)
+    try:
+        gpu = s.solve(P)
+    finally:
+        s.close()
+    assert_same_solution(gpu, oracle_for(cfg).solve_batch(P, threads=8))
+    monkeypatch.setenv("NMPC_PARK_MIN", "0")                      # migration off: the same bits
+    s = BatchSolver(cfg, max_batch=2600)
+    try:
+        off = s.solve(P)
+    finally:
+        s.close()
+    assert np.array_equal(off[0], gpu[0]) and np.array_equal(off[2]["reserved"], gpu[2]["reserved"])
+
+
 def test_solve_warm_start_multipliers_penalty(solvers):
     cfg = named_config("cfg1")
     s, o = solvers("cfg1"), oracle_for(cfg)
