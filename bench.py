@@ -33,7 +33,7 @@ PEAK_F64_VALU_TFLOPS = 78.6      # MI355X vector f64 (= f64 MFMA dense peak); MI
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of the cfg1 workload from rocprofv3 PMC passes (profiles/r01/pmc_fetch.csv,
 # pmc_write.csv: FETCH_SIZE x 1 KiB x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md] + WRITE_SIZE x 1 KiB)
-PMC_TRAFFIC_BYTES = {"cfg1": 2 * 20144.46875 * 1024 + 15951.171875 * 1024}     # FETCH_SIZE (KB) x 2 + WRITE_SIZE (KB)
+PMC_TRAFFIC_BYTES = {"cfg1": 2 * 27822.21875 * 1024 + 23941.234375 * 1024}     # FETCH_SIZE (KB) x 2 + WRITE_SIZE (KB)
 
 
 def flop_model(cfg):

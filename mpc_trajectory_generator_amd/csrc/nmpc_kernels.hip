@@ -40,7 +40,7 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
-    int par;     // 12 parked solver scalars (tri kernel)
+    int par;     // up to 16 parked solver scalars (tri / hybrid kernels)
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
@@ -990,7 +990,7 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     int o = 0;
     mp.sc = o;  o += 20;
     mp.cw = o;  o += nmpc::CW_NCOEF;
-    mp.par = o; o += 12;
+    mp.par = o; o += 16;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
     mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / tri kernels)

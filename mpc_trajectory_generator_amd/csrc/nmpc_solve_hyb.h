@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
 
+
     // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
     const unsigned hw_slot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4);
     const bool unfavoured = hw_slot != 0u;
@@ -179,21 +180,25 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         bool n_first = true, n_take_old = false;
         double n_H0 = 1;
         unsigned num_iter = 0;
-        const double *pks = pk + 6 * N;           // parked scalars
         const double c0 = a.c0 ? a.c0[inst] : 0.0;
-        double pen_c = resumed ? pks[0] : (c0 > 0.0 ? c0 : a.op.initial_penalty);
+        double pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
         double cbar_inv = 1.0 / fmax(pen_c, 1.0);          // 1 / max(c, 1), refreshed when c changes
         pk_c_lip = 0.0;                                     // 0.95 / (2 gamma), refreshed when gamma changes
         // scalars touched once per inner solve / outer iteration are parked in LDS (every lane writes the
         // same value) instead of occupying a VGPR pair each for the whole solve
-        pk_eps_nu = resumed ? pks[1] : a.op.initial_tolerance;
-        pk_dy_norm = resumed ? pks[2] : 0.0; pk_f2_norm = resumed ? pks[3] : 0.0;
-        pk_dy_norm_plus = resumed ? pks[4] : DBL_MAX; pk_f2_norm_plus = resumed ? pks[5] : 0.0;
-        pk_last_fpr = resumed ? pks[6] : 0.0; pk_last_cost = resumed ? pks[7] : 0.0; pk_norm_h = 0.0;
-        int nu = resumed ? (int)pks[8] : 0, inner_status = 0, state = D_INIT, final_status = 0;
-        unsigned inner_total = resumed ? (unsigned)pks[9] : 0u, n_cost = resumed ? (unsigned)pks[10] : 0u;
-        unsigned n_grad = resumed ? (unsigned)pks[11] : 0u, n_pass = resumed ? (unsigned)pks[12] : 0u;
+        pk_eps_nu = a.op.initial_tolerance;
+        pk_dy_norm = 0.0; pk_f2_norm = 0.0; pk_dy_norm_plus = DBL_MAX; pk_f2_norm_plus = 0.0; pk_last_fpr = 0.0; pk_last_cost = 0.0; pk_norm_h = 0.0;
+        int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
+        unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
         bool parked = false;
+        if (resumed) {                            // parked scalars
+            const double *pks = a.park + (size_t)inst * PS + 6 * N;
+            pen_c = pks[0];
+            cbar_inv = 1.0 / fmax(pen_c, 1.0);
+            pk_eps_nu = pks[1]; pk_dy_norm = pks[2]; pk_f2_norm = pks[3]; pk_dy_norm_plus = pks[4]; pk_f2_norm_plus = pks[5];
+            pk_last_fpr = pks[6]; pk_last_cost = pks[7];
+            nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
+        }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
@@ -603,6 +608,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #undef pk_H0
 #undef pk_sigma
 #undef pk_c_lip
+
 #undef NMPC_FETCH_GRAD
 #undef NMPC_TAKE_TRIAL
 #undef NMPC_HALF_STEP
