@@ -4,10 +4,15 @@
 One "step" = one cold-start solve (u0 = 0, y0 = 0, c0 = 1) of one batch of B = 8192 independent NMPC
 problems per GPU (default.yaml, N = 20, scene 11, 10 circle slots; BASELINE.json configs[1]),
 inputs already resident in HBM.  N > 1 GPUs: one process per GPU (torch.distributed, RCCL), each
-rank solves its own 8192-instance shard (weak scaling, no data-path collective) and the solutions
-are gathered over xGMI inside the step.
+rank solves its own 8192-instance shard (weak scaling, no data-path collective) and solutions,
+multipliers and status structs are gathered over xGMI inside the step
+(mpc_trajectory_generator_amd/dist.py: the same pack / gather / unpack the gloo test exercises).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4] [--batch B]
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
+``python -m torch.distributed.run`` with N ranks on 127.0.0.1 (and fails loudly when fewer than N GPUs
+are visible); launched by torchrun it checks that ``--gpus`` equals WORLD_SIZE.
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline      the bound that actually limits the kernel: f64 vector-ALU issue (78.6 TFLOP/s; the
@@ -15,12 +20,18 @@ Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
                 solver's own evaluation counters / the kernel's HIP-event time
   roofline_hbm  algorithmic HBM bytes per launch / the same time, against 8 TB/s (expected << 1 %)
   cpu_baseline  the CPU oracle (oracle/, kind "port": OpEn itself cannot be built here) timed on the
-                host cores on a bounded sample of the same batch, and checked bit-for-bit against
-                the GPU result for that sample.
+                host cores on a bounded sample of the same batch (dynamic work queue), with the
+                single-thread rate beside it, and checked bit-for-bit against the GPU result
+  seeds         the same batch recipe with seeds 1 and 2 (beside the timed seed 0): mean and range
+  warm_start    the same batch re-solved from the previous solution and multipliers
+  converged     throughput and iteration counts of the converged instances alone
+  solver_variant  the restatement switches in force
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +42,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_F64_VALU_TFLOPS = 78.6      # MI355X vector f64 (= f64 MFMA dense peak); MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per launch of the cfg1 workload from rocprofv3 PMC passes (profiles/r01/pmc_fetch.csv,
-# pmc_write.csv: FETCH_SIZE x 1 KiB x 2 [gfx950 wide-read correction, MI355X_MICROARCH.md] + WRITE_SIZE x 1 KiB)
-PMC_TRAFFIC_BYTES = {"cfg1": 2 * 27822.21875 * 1024 + 23941.234375 * 1024}     # FETCH_SIZE (KB) x 2 + WRITE_SIZE (KB)
 
 
 def flop_model(cfg):
@@ -43,6 +51,41 @@ def flop_model(cfg):
     f_bwd = N * (88 + 9 * Nobs + 16 * Ndyn)                                  # adjoint sweep, as implemented
     f_iter = 70 * cfg.n_u                                                    # L-BFGS two-loop + PANOC vector ops
     return f_fwd, f_bwd, f_iter
+
+
+def pmc_traffic(kernel_name, config, B, routes):
+    """HBM bytes per launch from the rocprofv3 PMC passes, looked up in profiles/*/traffic.json by kernel
+    name + hash of the kernel sources + workload: a figure measured on another version of the kernels
+    (or another workload) is never quoted -- the entry is then null."""
+    import glob
+    from mpc_trajectory_generator_amd import _lib
+    want = {"kernel": kernel_name, "source_hash": _lib.source_hash(), "config": config, "batch": B, "routes": routes}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
+        try:
+            entries = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in entries if isinstance(entries, list) else [entries]:
+            if all(e.get(k) == v for k, v in want.items()):
+                return float(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: launch N ranks of this script, one per GPU."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node; refusing to "
+                         "report a multi-GPU figure from fewer devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -58,21 +101,39 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra two-batches-in-flight measurement (kernel traces then hold the timed steps only)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip everything outside the contract's timed region (other seeds, warm start, pipelined, CPU leg)")
     ap.add_argument("--warm", action="store_true",
-                    help="warm start: every step starts from the previous step's solution and multipliers "
-                         "(SURVEY.md section 8d second timing); the headline metric is the cold start")
+                    help="warm start as the TIMED workload: every step starts from the previous step's solution and "
+                         "multipliers (SURVEY.md section 8d second timing); the headline metric is the cold start")
+    ap.add_argument("--budget", type=int, default=0,
+                    help="max_total_inner: deterministic stand-in for the reference's max_duration (0 = off, the headline)")
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_cpu_baseline = args.no_pipelined = True
+
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launched and args.gpus > 1:
+        respawn_under_torchrun(args)
 
     import torch
-    from mpc_trajectory_generator_amd import named_config
+    from mpc_trajectory_generator_amd import _lib, named_config
+    from mpc_trajectory_generator_amd import dist as shard
     from mpc_trajectory_generator_amd.harness import synthetic_batch
     from mpc_trajectory_generator_amd.solver import BatchSolver, status_from_bytes
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the solver has no CPU path")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -83,45 +144,65 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    use_dist = dist is not None
+
+    # rank 0 makes sure the library is built, the others wait for it (build_library also holds a file lock)
+    if rank == 0:
+        _lib.build_library()
+    if use_dist:
+        dist.barrier()
 
     cfg = named_config(args.config)
     B = args.batch
     kw = dict(synthetic_circles=(args.config in ("cfg3", "nobs50")), random_dyn=(args.config in ("cfg4", "smooth_velocity")))
-    routes = None
-    if args.routes > 0:                                                   # "randomized start/goal" (BASELINE.json configs[1])
-        from mpc_trajectory_generator_amd.frontend import random_routes
-        routes = random_routes(cfg, args.scene, args.routes, seed=1000 + rank)
-    P_host = synthetic_batch(cfg, args.scene, B, seed=rank, routes=routes, **kw)   # timing seeds 0..R-1
-    solver = BatchSolver(cfg, max_batch=B, device=local)
+
+    def make_batch(seed):
+        routes = None
+        if args.routes > 0:                                               # "randomized start/goal" (BASELINE.json configs[1])
+            from mpc_trajectory_generator_amd.frontend import random_routes
+            routes = random_routes(cfg, args.scene, args.routes, seed=1000 + seed)
+        return synthetic_batch(cfg, args.scene, B, seed=seed, routes=routes, **kw)
+
+    P_host = make_batch(rank)                                             # timing seeds 0..R-1
+    opts = {"max_total_inner": args.budget} if args.budget > 0 else {}
+    solver = BatchSolver(cfg, max_batch=B, device=local, **opts)
     d_p = torch.from_numpy(P_host).to(dev)
     d_u = torch.zeros(B, cfg.n_u, dtype=torch.float64, device=dev)
     d_y = torch.zeros(B, cfg.n1, dtype=torch.float64, device=dev)
     d_st = torch.zeros(B, 72, dtype=torch.uint8, device=dev)
-    use_dist = dist is not None
-    d_gather = torch.empty(world * B, cfg.n_u, dtype=torch.float64, device=dev) if use_dist else None
+    d_payload = torch.zeros(B, shard.payload_cols(cfg.n_u, cfg.n1), dtype=torch.float64, device=dev) if use_dist else None
+    d_gather = torch.empty(world * B, d_payload.shape[1], dtype=torch.float64, device=dev) if use_dist else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    d_y0 = torch.zeros(B, cfg.n1, dtype=torch.float64, device=dev)
 
-    d_y0 = torch.zeros(B, cfg.n1, dtype=torch.float64, device=dev) if args.warm else None
-
-    def step(i=None):
-        if args.warm:
+    def step(i=None, warm=args.warm, p=d_p):
+        if warm:
             d_y0.copy_(d_y)                           # warm start: previous solution (in place) and multipliers
         else:
             d_u.zero_()                               # cold start: u0 = 0 (the solver works in place)
         if i is not None:
             ev[i][0].record()
-        solver.solve_device(d_p, d_u, d_y0, None, d_y, d_st)
+        solver.solve_device(p, d_u, d_y0 if warm else None, None, d_y, d_st)
         if i is not None:
             ev[i][1].record()
-        if use_dist:
-            dist.all_gather_into_tensor(d_gather, d_u)          # result gather over xGMI (RCCL)
+        if use_dist:                                  # result gather over xGMI (RCCL): u | y | status, one collective
+            shard.pack_results(d_payload, d_u, d_y, d_st)
+            shard.gather_shards(d_payload, out=d_gather)
 
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def timed(n, **kws):
+        fence()
+        t = time.perf_counter()
+        for _ in range(n):
+            step(**kws)
+        fence()
+        return (time.perf_counter() - t) / n
 
     for _ in range(args.warmup):
         step()
@@ -136,11 +217,66 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # extra, outside the contract's timed region: the same K steps with TWO batches in flight (two handles,
-    # two streams, own result buffers) -- the tail of one batch overlaps the bulk of the next, which is how a
-    # service that receives batch after batch would run the solver.  Reported under "pipelined", never as `value`.
-    pipelined = None
-    if not use_dist and not args.warm and args.steps >= 2 and not args.no_pipelined:
+    st = status_from_bytes(d_st).copy()
+    u_gpu = d_u.cpu().numpy()
+    y_gpu = d_y.cpu().numpy()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    gather_ok = None
+    if use_dist:
+        # every rank's shard landed in its slot of the gathered payload, bit for bit
+        Ug, Yg, stg = shard.unpack_results(d_gather, world * B, world, cfg.n_u, cfg.n1, _lib.STATUS_DTYPE)
+        gather_ok = bool(np.array_equal(Ug[rank * B:(rank + 1) * B], u_gpu) and np.array_equal(Yg[rank * B:(rank + 1) * B], y_gpu)
+                         and stg[rank * B:(rank + 1) * B].tobytes() == st.tobytes())
+        assert gather_ok, "gathered payload does not hold this rank's results"
+        assert all((stg["num_inner_iterations"][r * B:(r + 1) * B] > 0).any() for r in range(world)), "a rank's slot is empty"
+
+    f_fwd, f_bwd, f_iter = flop_model(cfg)
+
+    def flops_of(s):
+        return float(s["num_cost_evals"].astype(np.float64).sum() * f_fwd
+                     + s["num_grad_evals"].astype(np.float64).sum() * (f_fwd + f_bwd)
+                     + s["num_inner_iterations"].astype(np.float64).sum() * f_iter)
+
+    flops = flops_of(st)
+    bytes_alg = float(B * (8 * (cfg.n_p + 2 * cfg.n_u + cfg.n1) + 72))
+    conv = st["exit_status"] == 0
+    stats = np.array([st["num_inner_iterations"].sum(), st["num_outer_iterations"].sum(), conv.sum(), B,
+                      st["num_inner_iterations"][conv].sum()], dtype=np.float64)
+    if use_dist:
+        ts_ = torch.from_numpy(stats).to(dev)
+        dist.all_reduce(ts_)
+        stats = ts_.cpu().numpy()
+
+    # ------------------------------------------------------------------ extras, all outside the timed region
+    extras_ok = not use_dist and not args.warm and not args.no_extras and args.budget == 0
+    seeds = warm = pipelined = None
+    if extras_ok:
+        # (a) seeds 1 and 2 of the same recipe: the launch-order heuristic must not be fit to seed 0
+        per_seed = {"0": 1e3 * elapsed / args.steps}
+        for sd in (1, 2):
+            d_ps = torch.from_numpy(make_batch(sd)).to(dev)
+            step(p=d_ps)
+            per_seed[str(sd)] = 1e3 * timed(2, p=d_ps)
+            del d_ps
+        ms = np.array(list(per_seed.values()))
+        seeds = {"ms_per_step": per_seed, "mean_ms": float(ms.mean()), "min_ms": float(ms.min()), "max_ms": float(ms.max()),
+                 "mean_solves_per_s": float(B / (ms.mean() * 1e-3)),
+                 "note": "seed 0 is the timed workload (`value`); seeds 1, 2: one untimed + two timed steps each"}
+        # (b) warm start: the batch re-solved from the previous solution and multipliers (c0 = 1)
+        step(warm=False)
+        step(warm=True)
+        wms = 1e3 * timed(2, warm=True)
+        stw = status_from_bytes(d_st)
+        warm = {"value": B / (wms * 1e-3), "unit": "solves/s", "ms_per_step": wms,
+                "mean_inner_iters": float(stw["num_inner_iterations"].mean()),
+                "converged_frac": float((stw["exit_status"] == 0).mean()),
+                "roofline_frac": flops_of(stw) / (wms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS}
+        step(warm=False)                                                   # leave the cold-start results in the buffers
+        fence()
+    # (c) the same K steps with TWO batches in flight (two handles, two streams, own result buffers): the tail
+    # of one batch overlaps the bulk of the next, which is how a service that receives batch after batch would
+    # run the solver.  Reported under "pipelined", never as `value`.
+    if extras_ok and args.steps >= 2 and not args.no_pipelined:
         solver2 = BatchSolver(cfg, max_batch=B, device=local)
         bufs = [(solver, d_u, d_y, d_st, torch.cuda.Stream(dev)),
                 (solver2, torch.zeros_like(d_u), torch.zeros_like(d_y), torch.zeros_like(d_st), torch.cuda.Stream(dev))]
@@ -157,31 +293,15 @@ def main():
         pipelined = {"inflight": 2, "value": B * args.steps / tp, "unit": "solves/s", "ms_per_step": 1e3 * tp / args.steps}
         solver2.close()
 
-    st = status_from_bytes(d_st)
-    u_gpu = d_u.cpu().numpy()
-    y_gpu = d_y.cpu().numpy()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    f_fwd, f_bwd, f_iter = flop_model(cfg)
-    flops = float(st["num_cost_evals"].astype(np.float64).sum() * f_fwd
-                  + st["num_grad_evals"].astype(np.float64).sum() * (f_fwd + f_bwd)
-                  + st["num_inner_iterations"].astype(np.float64).sum() * f_iter)
-    bytes_alg = float(B * (8 * (cfg.n_p + 2 * cfg.n_u + cfg.n1) + 72))
-    stats = np.array([st["num_inner_iterations"].sum(), st["num_outer_iterations"].sum(),
-                      (st["exit_status"] == 0).sum(), B], dtype=np.float64)
-    if use_dist:
-        ts_ = torch.from_numpy(stats).to(dev)
-        dist.all_reduce(ts_)
-        stats = ts_.cpu().numpy()
-
-    if use_dist and world > 1:
-        assert torch.equal(d_gather[rank * B:(rank + 1) * B], d_u)      # own shard landed in its slot
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
         return
 
+    traffic, traffic_src = pmc_traffic(solver.kernel_name, args.config, B, args.routes) if not args.warm else (None, None)
+    value = world * B * args.steps / elapsed
     out = {
-        "metric": "nmpc_solves_per_sec", "value": world * B * args.steps / elapsed, "unit": "solves/s",
+        "metric": "nmpc_solves_per_sec", "value": value, "unit": "solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -189,35 +309,43 @@ def main():
                                f"Ndynobs={cfg.Ndynobs}, scene {args.scene} ({args.routes or 1} route(s): "
                                f"{'randomised start/goal planned by the visibility-graph front-end' if args.routes else 'scene start->end'}), "
                                f"batch={B}/GPU, {'WARM start (previous solution and multipliers, c0=1)' if args.warm else 'cold start (u0=0, y0=0, c0=1)'}, "
-                               f"tol 1e-4, caps inner {solver.opts.max_inner}/outer {solver.opts.max_outer}",
-                   "batch_per_gpu": B, "n_u": cfg.n_u, "n_p": cfg.n_p, "parallelism": f"instance-sharded x{world}"},
+                               f"tol 1e-4, caps inner {solver.opts.max_inner}/outer {solver.opts.max_outer}"
+                               + (f", inner-iteration budget {args.budget} per solve (NotConvergedOutOfTime beyond it)" if args.budget else ""),
+                   "batch_per_gpu": B, "n_u": cfg.n_u, "n_p": cfg.n_p, "parallelism": f"instance-sharded x{world}",
+                   "gather": "one RCCL all_gather of u|y|status per step" if use_dist else "none (single GPU)"},
+        "solver_variant": solver.variant,
         "mean_inner_iters": stats[0] / stats[3], "mean_outer_iters": stats[1] / stats[3],
         "converged_frac": stats[2] / stats[3],
-        "pipelined": pipelined,
+        # the headline counts every solve, converged or not (a non-converged solve still returns the controls the
+        # reference would apply, src/path_generator.py:393-394); the converged ones alone:
+        "converged": {"value": value * stats[2] / stats[3], "unit": "converged solves/s",
+                      "mean_inner_iters": stats[4] / max(stats[2], 1.0)},
+        "gather_checked": gather_ok,
+        "seeds": seeds, "warm_start": warm, "pipelined": pipelined,
         "p50_inner_iters": float(np.median(st["num_inner_iterations"])),
         "p99_inner_iters": float(np.percentile(st["num_inner_iterations"], 99)),
         "max_inner_iters": int(st["num_inner_iterations"].max()),
+        "critical_instance": {"passes": int(st["reserved"].max()), "us_per_pass_if_alone": 1e3 * kern_ms / max(int(st["reserved"].max()), 1),
+                              "mean_passes": float(st["reserved"].mean())},
         # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s);
         # the kernel issues no MFMA -- "bound_detail" says what actually limits it
         "roofline": {"bound": "mfma", "bound_detail": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
-                     "traffic": PMC_TRAFFIC_BYTES.get(args.config) if (B == 8192 and args.routes == 32 and not args.warm) else None,
-                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01)",
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)", "traffic_source": traffic_src,
                      "kernel": solver.kernel_name, "kernel_ms": kern_ms,
                      "flops_per_launch": flops,
                      "note": "f64 vector-ALU issue bounds this kernel, not HBM or MFMA (SURVEY.md section 8d); "
                              "MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},
         "roofline_hbm": {"bound": "hbm", "achieved": bytes_alg / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": PMC_TRAFFIC_BYTES.get(args.config) if (B == 8192 and args.routes == 32) else None, "bytes_per_launch": bytes_alg,
-                         "traffic_source": "profiles/r01/pmc_fetch.csv + pmc_write.csv (separate --pmc passes)"},
+                         "traffic": traffic, "bytes_per_launch": bytes_alg, "traffic_source": traffic_src},
     }
 
     if not args.no_cpu_baseline and not args.warm:
         # CPU leg: the oracle on the host cores, bounded sample of the same batch (rank 0, any N)
         from oracle import Oracle
         orc = Oracle(cfg.N_hor, cfg.Nobs, cfg.Ndynobs, cfg.ts, cfg.lin_vel_min, cfg.lin_vel_max, cfg.ang_vel_max,
-                     cfg.lin_acc_min, cfg.lin_acc_max, cfg.ang_acc_max)
+                     cfg.lin_acc_min, cfg.lin_acc_max, cfg.ang_acc_max, **solver.oracle_opts())
         cores = os.cpu_count() or 1
         n0 = min(B, 4 * cores)
         t = time.perf_counter()
@@ -230,9 +358,14 @@ def main():
         same = bool(np.array_equal(uo, u_gpu[:n]) and np.array_equal(yo, y_gpu[:n])
                     and np.array_equal(sto["num_inner_iterations"], st["num_inner_iterations"][:n])
                     and np.array_equal(sto["exit_status"], st["exit_status"][:n]))
+        n1t = int(min(n, max(4, (rate / cores) * 4.0)))          # about 4 s on one thread
+        t = time.perf_counter()
+        orc.solve_batch(P_host[:n1t], threads=1)
+        dt1 = time.perf_counter() - t
         out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-                               "sample": f"first {n} instances of the rank-0 batch, {cores} host threads, "
-                                         f"{dt:.1f} s; oracle/nmpc_oracle.c (restatement; OpEn not buildable)",
+                               "sample": f"first {n} instances of the rank-0 batch, {cores} host threads pulling from a "
+                                         f"shared work queue, {dt:.1f} s; oracle/nmpc_oracle.c -O3 (restatement; OpEn not buildable)",
+                               "single_thread": {"value": n1t / dt1, "unit": "solves/s", "sample": f"first {n1t} instances, {dt1:.1f} s"},
                                "mean_inner_iters": float(sto["num_inner_iterations"].mean()),
                                "gpu_bitwise_equal_on_sample": same}
     print(json.dumps(out))

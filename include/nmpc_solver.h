@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define NMPC_ABI_VERSION 1
+#define NMPC_ABI_VERSION 2
 
 typedef enum nmpc_error {
     NMPC_OK = 0,
@@ -62,7 +62,8 @@ typedef struct nmpc_problem {
 
 /* OpEn solver configuration (src/mpc/mpc_generator.py:184-186; opengen defaults otherwise).
  * Deviation: the reference stops on wall-clock (max_duration 0.5 s, :9,186); a batch must be
- * deterministic, so only the iteration caps apply. */
+ * deterministic, so the iteration caps apply, plus -- when asked for -- max_total_inner, the
+ * deterministic stand-in for max_duration. */
 typedef struct nmpc_opts {
     double tolerance;            /* 1e-4 */
     double initial_tolerance;    /* 1e-4 */
@@ -74,13 +75,26 @@ typedef struct nmpc_opts {
     int32_t lbfgs_memory;        /* 10 (1..10) */
     int32_t max_inner;           /* 500  */
     int32_t max_outer;           /* 10   */
+    int32_t max_total_inner;     /* 0 = off.  PANOC iterations one solve may spend in total; beyond it the
+                                    solve returns the feasible half step with NMPC_NOT_CONVERGED_OUT_OF_TIME
+                                    (what max_duration does in the reference, src/mpc/mpc_generator.py:9,186,
+                                    configs/default.yaml:49, counted in iterations instead of microseconds) */
+    /* Restatement switches: choices of the PANOC/ALM restatement that cannot be checked against OpEn
+     * here.  0 = what every published figure of this project uses unless it
+     * says otherwise; oracle and kernels implement all of them, bit for bit. */
+    int32_t akkt_gradient;       /* "previous gradient" of the AKKT residual ||r/gamma + grad - grad_prev||:
+                                    0 cached before every line-search trial, carried across inner solves
+                                    1 cached at the top of step() from iteration 1 on, zero at iteration 0
+                                    2 no AKKT test (PANOC stops on ||r|| < tolerance alone)                 */
+    int32_t ls_failure;          /* all 11 line-search trials fail: 0 take the last one, 1 tau = 0 (FB step) */
+    int32_t inner_status;        /* outer criteria hold: 0 report the last inner status, 1 report Converged */
     int32_t reserved;
 } nmpc_opts;
 
 typedef enum nmpc_exit {
     NMPC_CONVERGED = 0,
     NMPC_NOT_CONVERGED_ITERATIONS = 1,
-    NMPC_NOT_CONVERGED_OUT_OF_TIME = 2,      /* never produced (no wall-clock stop)          */
+    NMPC_NOT_CONVERGED_OUT_OF_TIME = 2,      /* opts.max_total_inner spent (deterministic max_duration) */
     NMPC_NOT_CONVERGED_COST = 3,
     NMPC_NOT_CONVERGED_NOT_FINITE = 4
 } nmpc_exit;

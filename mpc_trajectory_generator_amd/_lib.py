@@ -42,7 +42,16 @@ class NmpcOpts(C.Structure):
                 ("delta_tolerance", C.c_double), ("initial_penalty", C.c_double),
                 ("penalty_update", C.c_double), ("tolerance_update", C.c_double),
                 ("sufficient_decrease", C.c_double), ("lbfgs_memory", C.c_int32),
-                ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("reserved", C.c_int32)]
+                ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("max_total_inner", C.c_int32),
+                ("akkt_gradient", C.c_int32), ("ls_failure", C.c_int32), ("inner_status", C.c_int32),
+                ("reserved", C.c_int32)]
+
+# the restatement switches (include/nmpc_solver.h) and what their values mean
+VARIANT_FIELDS = {
+    "akkt_gradient": ("per_trial", "step_top", "off"),
+    "ls_failure": ("take_last_trial", "tau0_fb_step"),
+    "inner_status": ("propagate_inner", "converged_if_outer_ok"),
+}
 
 
 class NmpcRoute(C.Structure):
@@ -63,16 +72,47 @@ STATUS_DTYPE = np.dtype([("exit_status", "<i4"), ("num_outer_iterations", "<u4")
 assert STATUS_DTYPE.itemsize == 72
 
 
-def build_library(force: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 the kernels in-tree (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("nmpc_kernels.hip", "nmpc_device.h", "nmpc_solve_dual.h", "nmpc_solve_tri.h", "nmpc_solve_hyb.h", "nmpc_loop.h", "Makefile")]
+def _sources():
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "nmpc_solver.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
-        r = subprocess.run(["make", "-C", _CSRC, "-B", "libnmpc_hip.so"], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("building libnmpc_hip.so failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+    return srcs
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources: the key profiles/*/traffic.json files are stored under, so that a
+    PMC figure measured on one version of the kernels is never quoted for another."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in _sources():
+        if not s.endswith("Makefile"):
+            with open(s, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 the kernels in-tree (cross-compiles without a GPU).  Safe to call from
+    several processes at once (one rank per GPU): the build runs under a file lock into a temporary name
+    and is renamed into place, the other processes find a fresh library when they get the lock."""
+    import fcntl
+
+    def stale():
+        return (not os.path.exists(LIB_PATH)) or any(
+            os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in _sources())
+
+    if not (force or stale()):
+        return LIB_PATH
+    with open(os.path.join(_CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                tmp = f"libnmpc_hip.so.tmp{os.getpid()}"
+                r = subprocess.run(["make", "-C", _CSRC, "-B", tmp, f"OUT={tmp}"], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("building libnmpc_hip.so failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+                os.replace(os.path.join(_CSRC, tmp), LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -40,12 +40,12 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
-    int par;     // up to 16 parked solver scalars (tri / hybrid kernels)
+    int par;     // up to 16 parked solver scalars (hybrid kernel)
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x P per-stage ellipse data
-    int vec;     // 6 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed
+    int vec;     // 7 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed, grad at u_k
     int rho;     // m
     int S, Y;    // m slots x N lanes x (v, w)
     int total;
@@ -527,6 +527,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     // horizon vectors: (v, w) pair per lane
     double uv = 0, uw = 0, gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0;   // u, grad, grad-step, half-step, gamma*fpr
     double dv = 0, dw = 0, pv = 0, pw = 0, qv = 0, qw = 0;                                      // direction, u_plus, previous gradient
+    double gkv = 0, gkw = 0;                                                                    // gradient at the current iterate (ls_failure = 1)
+    bool timed_out = false;
     double osv = 0, osw = 0, ogv = 0, ogw = 0;                                                  // L-BFGS old state / old gamma*fpr
     double yv = 0, yw = 0, ypv = 0, ypw = 0;                                                    // multipliers y, y_plus
     double zv = 0, zw = 0;                                                                      // query point of the next evaluation
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 eps_nu = a.op.initial_tolerance;
                 dy_norm = f2_norm = f2_norm_plus = 0.0;
                 dy_norm_plus = DBL_MAX;
-                nu = 0; inner_total = 0; n_cost = 0; n_grad = 0; inner_status = 0;
+                nu = 0; inner_total = 0; n_cost = 0; n_grad = 0; inner_status = 0; timed_out = false;
                 qv = qw = 0.0;                       // gradient_u_previous starts at zero for every solve
                 // outer iteration 0: y <- Pi_Y(y), start PANOC
                 yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);
@@ -691,6 +693,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                     pv = fma(-tau, dv, fma(-omt, rv, uv));
                     pw = fma(-tau, dw, fma(-omt, rw, uw));
                     qv = gv; qw = gw;                              // cache_previous_gradient
+                    gkv = gv; gkw = gw;
                     zv = pv; zw = pw; need_grad = true;
                     state = ST_LS;
                 }
@@ -719,6 +722,15 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 pw = fma(-tau, dw, fma(-omt, rw, uw));
                 qv = gv; qw = gw;
                 zv = pv; zw = pw; need_grad = true;                // stay in ST_LS
+            } else if (lhs > rhs_ls && a.op.ls_failure == 1) {
+                // every trial failed, tau = 0: forward-backward step from the current iterate
+                tau = 0.0;
+                gv = gkv; gw = gkw;
+                sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
+                uv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
+                uw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
+                zv = uv; zw = uw; need_grad = true;
+                state = ST_FB0;
             } else {
                 uv = pv; uw = pw;
                 end_iter = true;
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
             const bool crit2 = a.n2 == 0 || f2_norm_plus <= a.op.delta_tolerance + SMALL;
             const bool crit3 = eps_nu <= a.op.tolerance + SMALL;
             if (crit1 && crit2 && crit3) {
-                finished = true; final_status = inner_status;
+                finished = true; final_status = a.op.inner_status == 1 ? NMPC_CONVERGED : inner_status;
             } else {
                 const bool stall = nu == 0 || (dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
                                                f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
@@ -748,6 +760,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
                 nu++;
                 if (nu == a.op.max_outer) { finished = true; final_status = NMPC_NOT_CONVERGED_ITERATIONS; }
+                else if (timed_out) { finished = true; final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; nu--; }   // (the report below adds the one back)
                 else start_panoc = true;
             }
         }
@@ -756,26 +769,36 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
             iteration++;
             // OpEn: while step() && num_iter < max_iter { num_iter++ }
             if (!(num_iter < (unsigned)a.op.max_inner)) inner_done = true;
-            else { num_iter++; begin_step = true; }
+            else {
+                num_iter++;
+                if (a.op.max_total_inner > 0 && inner_total + num_iter >= (unsigned)a.op.max_total_inner) { timed_out = true; inner_done = true; }
+                else begin_step = true;
+            }
         }
         if (begin_step) {
             rv = uv - hv; rw = uw - hw;
             nr2 = hdot<P>(rv, rw, rv, rw, lane);
             norm_r = sqrt(nr2);
             bool exit_now = false;
-            if (norm_r < a.op.tolerance) {                         // fpr test, then the AKKT test
-                const double a1 = rv / gamma + (gv - qv), a2 = rw / gamma + (gw - qw);
-                exit_now = sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu;
+            if (norm_r < a.op.tolerance) {                         // fpr test, then the AKKT test (opts.akkt_gradient)
+                if (a.op.akkt_gradient == 2) exit_now = true;
+                else {
+                    const bool top = a.op.akkt_gradient == 1;      // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
+                    const double b1 = top ? (iteration >= 1 ? 0.0 : gv) : gv - qv, b2 = top ? (iteration >= 1 ? 0.0 : gw) : gw - qw;
+                    const double a1 = rv / gamma + b1, a2 = rw / gamma + b2;
+                    exit_now = sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu;
+                }
             }
             if (exit_now) inner_done = true;
             else { lip_it = 0; zv = hv; zw = hw; need_grad = false; state = ST_LIP; }
         }
         if (inner_done) {
-            inner_status = num_iter < (unsigned)a.op.max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
+            inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
+                                     : (num_iter < (unsigned)a.op.max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
             inner_total += num_iter;
             last_fpr = norm_r; last_cost = cost;
             uv = hv; uw = hw;                                      // PANOC returns the feasible half step
-            const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
+            const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
             if (group_sum<P>((in && !fin) ? 1.0 : 0.0, lane) > 0.0) {
                 finished = true; final_status = NMPC_NOT_CONVERGED_NOT_FINITE;
             } else {
@@ -821,7 +844,6 @@ namespace nmpc {
 __host__ __device__ inline int park_stride(int N) { return 6 * N + 16; }
 }
 #include "nmpc_solve_dual.h"
-#include "nmpc_solve_tri.h"
 #include "nmpc_solve_hyb.h"
 #include "nmpc_loop.h"
 
@@ -931,7 +953,6 @@ struct nmpc_handle {
     bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
     bool shape_nobs50;     // ... == ShapeNobs50
     bool shape_n40;        // ... == ShapeN40
-    bool hybrid;           // P == 20: solver state in the two-half layout, evaluation in the tri layout (nmpc_solve_hyb.h)
     int grid_cap;          // resident waves the launch is sized for
     unsigned int *d_queue;
     int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
@@ -960,6 +981,10 @@ void nmpc_default_opts(nmpc_opts *o)
     o->lbfgs_memory = 10;
     o->max_inner = 500;
     o->max_outer = 10;
+    o->max_total_inner = 0;
+    o->akkt_gradient = 0;
+    o->ls_failure = 0;
+    o->inner_status = 0;
     o->reserved = 0;
 }
 
@@ -993,12 +1018,12 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     mp.par = o; o += 16;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
-    mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / tri kernels)
+    mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / hybrid kernels)
     mp.rho = o; o += m;
     const int cols = P == 20 ? 32 : P;                // >= nmpc::lay_cols; the hybrid kernel parks 32 state-layout columns
     mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * cols;
     o = (o + 1) & ~1;
-    mp.vec = o; o += 6 * 2 * cols;
+    mp.vec = o; o += 7 * 2 * cols;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
     mp.S = o;   o += 2 * (pb.N + 1) * m;        // (+1: the hybrid kernel keeps an all-zero column per slot)
     mp.Y = o;   o += 2 * (pb.N + 1) * m;
@@ -1014,7 +1039,9 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         return NMPC_ERR_BAD_PROBLEM;
     nmpc_opts op;
     if (opts) op = *opts; else nmpc_default_opts(&op);
-    if (op.lbfgs_memory < 1 || op.lbfgs_memory > nmpc::MAXMEM || op.max_inner < 1 || op.max_outer < 1)
+    if (op.lbfgs_memory < 1 || op.lbfgs_memory > nmpc::MAXMEM || op.max_inner < 1 || op.max_outer < 1 ||
+        op.max_total_inner < 0 || op.akkt_gradient < 0 || op.akkt_gradient > 2 || op.ls_failure < 0 || op.ls_failure > 1 ||
+        op.inner_status < 0 || op.inner_status > 1)
         return NMPC_ERR_BAD_OPTS;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
@@ -1022,10 +1049,8 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true;
     h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : 64);
-    h->hybrid = true;
-    if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments: force the two-point layout / the all-tri kernel
+    if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments / cross-checks: force the two-point layout
         if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
-        if (!strcmp(env, "tri")) h->hybrid = false;
     }
     h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
@@ -1084,12 +1109,9 @@ const char *nmpc_last_error(const nmpc_handle *h) { return h ? h->err.c_str() : 
 const char *nmpc_kernel_name(const nmpc_handle *h)
 {
     if (!h) return "";
-    if (h->P == 20 && h->hybrid)
+    if (h->P == 20)
         return h->shape_default ? "nmpc_solve_hyb_kernel<ShapeDefault>"
                                 : (h->shape_nobs50 ? "nmpc_solve_hyb_kernel<ShapeNobs50>" : "nmpc_solve_hyb_kernel<ShapeAny>");
-    if (h->P == 20)
-        return h->shape_default ? "nmpc_solve_tri_kernel<ShapeDefault>"
-                                : (h->shape_nobs50 ? "nmpc_solve_tri_kernel<ShapeNobs50>" : "nmpc_solve_tri_kernel<ShapeAny>");
     return h->P == 32 ? "nmpc_solve_dual_kernel" : (h->shape_n40 ? "nmpc_solve_kernel<64, ShapeN40>" : "nmpc_solve_kernel<64>");
 }
 
@@ -1123,7 +1145,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
         hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
         a.order = h->d_order;
-        if (h->P == 20 && h->hybrid && h->park_min > 0) {      // two waves per SIMD: long-runners migrate to the favoured one
+        if (h->P == 20 && h->park_min > 0) {      // two waves per SIMD: long-runners migrate to the favoured one
             if (!h->d_park) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_park, (size_t)h->max_batch * nmpc::park_stride(h->pb.N) * 8));
                 HIP_TRY(h, hipMalloc((void **)&h->d_pool, (size_t)h->max_batch * sizeof(int)));
@@ -1140,12 +1162,9 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
-    if (h->P == 20 && h->hybrid && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20 && h->hybrid && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20 && h->hybrid) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20 && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_tri_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
+    if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20 && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
+    else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else if (h->shape_n40) hipLaunchKernelGGL((nmpc::nmpc_solve_kernel<64, nmpc::ShapeN40>), dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);

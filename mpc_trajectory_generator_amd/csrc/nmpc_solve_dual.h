@@ -26,7 +26,7 @@ __device__ __forceinline__ void both_halves(double v, double &from_h0, double &f
     from_h1 = __hiloint2double(hi[1], lo[1]);
 }
 
-enum : int { D_INIT = 0, D_LIP, D_ITER, D_LS, D_ALM };
+enum : int { D_INIT = 0, D_LIP, D_ITER, D_LS, D_ALM, D_FB };
 
 // unconditional LDS load of a (v, w) pair, zeroed for lanes beyond the horizon
 __device__ __forceinline__ dbl2 ld_pair(const lds_double2 *base, int idx, bool keep)
@@ -71,8 +71,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
     lds_double *Lrho = L + a.map.rho;
     lds_double2 *Los = (lds_double2 *)(L + a.map.vec) + t;      // parked pairs, one column per stage
     lds_double2 *Log = Los + P, *Lq = Los + 2 * P, *Lyp = Los + 3 * P;
+    lds_double2 *Lgk = Los + 6 * P;                             // gradient at the current iterate (opts.ls_failure = 1 only)
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
+    const unsigned budget = (unsigned)a.op.max_total_inner;     // 0 = off
 
     for (;;) {
         // ------------------------------------------------------------------ next instance from the queue
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
-        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
-        bool running = true;
+        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
+        bool running = true, timed_out = false;
 #ifdef NMPC_PROFILE
         { extern __shared__ long long nmpc_prof_lds[]; if (lane < 16) nmpc_prof_lds[4096 + lane] = 0; }
         long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
@@ -151,13 +153,27 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 pw = fma(-th_, dw, fma(-omt, rw, uw));
                 zv = pv; zw = pw; need_grad = true; state = D_LS;
             }
+            // ---------------------------------------------------------------- every trial failed (opts.ls_failure = 1):
+            // tau = 0, the forward-backward step from the current iterate
+            if (f_fb) {
+                f_fb = false;
+                tau = 0.0;
+                { const dbl2 gk_ = *Lgk; gv = gk_.x; gw = gk_.y; }
+                NMPC_HALF_STEP(uv, uw);
+                zv = hv; zw = hw; need_grad = true; state = D_FB;
+            }
             // ---------------------------------------------------------------- an iteration finished
             if (f_end) {
                 f_end = false;
                 iteration++;
                 // OpEn: while step() && num_iter < max_iter { num_iter++ }
                 if (!(num_iter < max_inner)) f_done = true;
-                else { num_iter++; f_begin = true; }
+                else {
+                    num_iter++;
+                    // opts.max_total_inner: the deterministic max_duration
+                    if (budget > 0u && inner_total + num_iter >= budget) { timed_out = true; f_done = true; }
+                    else f_begin = true;
+                }
             }
             // ---------------------------------------------------------------- start of a PANOC step
             if (f_begin) {
@@ -166,10 +182,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 nr2 = hdot<P>(rv, rw, rv, rw, lane);
                 norm_r = sqrt(nr2);
                 bool exit_now = false;
-                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test
-                    const dbl2 q_ = *Lq;
-                    const double a1 = rv / gamma + (gv - q_.x), a2 = rw / gamma + (gw - q_.y);
-                    exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu);
+                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
+                    if (a.op.akkt_gradient == 2) exit_now = true;
+                    else {
+                        const dbl2 q_ = *Lq;
+                        const bool top = a.op.akkt_gradient == 1;       // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
+                        const double b1 = top ? (iteration >= 1 ? 0.0 : gv) : gv - q_.x;
+                        const double b2 = top ? (iteration >= 1 ? 0.0 : gw) : gw - q_.y;
+                        const double a1 = rv / gamma + b1, a2 = rw / gamma + b2;
+                        exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu);
+                    }
                 }
                 if (exit_now) {
                     f_done = true;
@@ -277,11 +299,12 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
             // ---------------------------------------------------------------- the inner solver returned
             if (f_done) {
                 f_done = false;
-                inner_status = num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
+                inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
+                                         : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
                 inner_total += num_iter;
                 last_fpr = norm_r; last_cost = cost;
                 uv = hv; uw = hw;                                        // PANOC returns the feasible half step
-                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
+                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
                 if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
                 else { zv = uv; zw = uw; need_grad = false; state = D_ALM; }
             }
@@ -360,18 +383,20 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                             dv = rv; dw = rw;                            // empty buffer: d = r
                             rhs_ls = NMPC_FBE(uv, uw) - sigma * nr2;
                             tau = 1.0; ls_n = 0;
+                            if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
                             f_trials = true;
                         }
                     } else {
                         lb_first = n_first; lb_head = n_head; lb_active = n_active; H0 = n_H0;      // commit
                         if (n_take_old) { *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw}; }
                         n_grad++;
+                        if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
                         *Lq = dbl2{gv, gw};                              // cache_previous_gradient
                         cost = psiB; gv = gBv; gw = gBw;
                         NMPC_HALF_STEP(pv, pw);
                         const double lhs = NMPC_FBE(pv, pw);
                         if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; }
-                        else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+                        else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }      // (tau = 1 is never the last trial)
                     }
                 }
             } else if (state == D_LS) {
@@ -386,7 +411,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 NMPC_HALF_STEP(pv, pw);
                 double lhs = NMPC_FBE(pv, pw);
                 bool accept = true;
-                if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) {
+                bool bad = __any(lhs > rhs_ls);
+                if (bad && ls_n < MAX_LINESEARCH_ITERATIONS) {
                     tau /= 2.0; ls_n++;
                     n_grad++;
                     *Lq = dbl2{gv, gw};
@@ -394,9 +420,19 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     pv = pBv; pw = pBw;
                     NMPC_HALF_STEP(pv, pw);
                     lhs = NMPC_FBE(pv, pw);
-                    if (__any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; accept = false; }
+                    bad = __any(lhs > rhs_ls);
+                    if (bad && ls_n < MAX_LINESEARCH_ITERATIONS) { tau /= 2.0; ls_n++; f_trials = true; accept = false; }
                 }
-                if (accept) { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+                if (accept && bad && a.op.ls_failure == 1) f_fb = true;        // the last trial failed too: tau = 0
+                else if (accept) { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+            } else if (state == D_FB) {
+                // psi, grad psi at u_bar: the plain forward-backward step (as in iteration 0)
+                n_grad++;
+                uv = hv; uw = hw;
+                cost = psiA; gv = gAv; gw = gAw;
+                NMPC_HALF_STEP(uv, uw);
+                fbe_ok = false;
+                f_end = true;
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
@@ -411,7 +447,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                 const bool crit2 = a.n2 == 0 || __any(f2_norm_plus <= a.op.delta_tolerance + SMALL);
                 const bool crit3 = __any(eps_nu <= a.op.tolerance + SMALL);
                 if (crit1 && crit2 && crit3) {
-                    final_status = inner_status; running = false;
+                    final_status = a.op.inner_status == 1 ? NMPC_CONVERGED : inner_status; running = false;
                 } else {
                     const bool stall = nu == 0 || __any(dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
                                                         f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
@@ -421,6 +457,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
+                    else if (timed_out) { final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; running = false; nu--; }      // (the report adds the one back)
                     else f_start = true;
                 }
             }

@@ -27,6 +27,14 @@
 
 namespace nmpc {
 
+// a query point's scalar (psi): every lane of the point's row holds it; rows 0..2 are points 0..2
+__device__ __forceinline__ double point_scalar(double v, int k)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * k);
+    return __hiloint2double(hi, lo);
+}
+
 // gradient pair of query point k's evaluation, delivered to the state layout (zero beyond the horizon)
 #define NMPC_FETCH_GRAD(SRC, OV, OW)                                           \
     do {                                                                       \
@@ -95,13 +103,15 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
     lds_double *Lrho = L + a.map.rho;
     lds_double2 *Los = (lds_double2 *)(L + a.map.vec) + t;      // parked pairs, one column per stage
     lds_double2 *Log = Los + COLS, *Lq = Los + 2 * COLS, *Lyp = Los + 3 * COLS;
+    lds_double2 *Lgk = Los + 6 * COLS;                          // gradient at the current iterate (opts.ls_failure = 1 only)
     lds_double2 *LypE = (lds_double2 *)(L + a.map.vec) + 3 * COLS + te;      // the same columns, by evaluation lane
     lds_double2 *Ly = (lds_double2 *)(L + a.map.vec) + 4 * COLS + te;        // multipliers y (read by every evaluation)
     lds_double *Lvr = L + a.map.vec + 2 * 5 * COLS + te;                     // reference speed of this stage
-    if (lane < MAXMEM) { LS[lane * NS + N] = dbl2{0.0, 0.0}; LY[lane * NS + N] = dbl2{0.0, 0.0}; }
+    if (lane < m) { LS[lane * NS + N] = dbl2{0.0, 0.0}; LY[lane * NS + N] = dbl2{0.0, 0.0}; }
     NMPC_WAVE_SYNC();
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
+    const unsigned budget = (unsigned)a.op.max_total_inner;     // 0 = off
     lds_double *Lpar = L + a.map.par;
 #define pk_eps_nu Lpar[0]
 #define pk_dy_norm Lpar[1]
@@ -201,8 +211,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
-        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false;
-        bool running = true;
+        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
+        bool running = true, timed_out = false;
 #ifdef NMPC_PROFILE
         { extern __shared__ long long nmpc_prof_lds[]; if (lane < 16) nmpc_prof_lds[4096 + lane] = 0; }
         long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
@@ -237,13 +247,27 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 yqw = fma(-t4_, dw, fma(-om4_, rw, uw));
                 need_grad = true; state = D_LS;
             }
+            // ---------------------------------------------------------------- every trial failed (opts.ls_failure = 1):
+            // tau = 0, the forward-backward step from the current iterate
+            if (f_fb) {
+                f_fb = false;
+                tau = 0.0;
+                { const dbl2 gk_ = *Lgk; gv = gk_.x; gw = gk_.y; }
+                NMPC_HALF_STEP(uv, uw);
+                xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
+            }
             // ---------------------------------------------------------------- an iteration finished
             if (f_end) {
                 f_end = false;
                 iteration++;
                 // OpEn: while step() && num_iter < max_iter { num_iter++ }
                 if (!(num_iter < max_inner)) f_done = true;
-                else { num_iter++; f_begin = true; }
+                else {
+                    num_iter++;
+                    // opts.max_total_inner: the deterministic max_duration
+                    if (budget > 0u && inner_total + num_iter >= budget) { timed_out = true; f_done = true; }
+                    else f_begin = true;
+                }
             }
             // ---------------------------------------------------------------- start of a PANOC step
             if (f_begin) {
@@ -252,10 +276,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 nr2 = hdot<P>(rv, rw, rv, rw, lane);
                 norm_r = sqrt(nr2);
                 bool exit_now = false;
-                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test
-                    const dbl2 q_ = *Lq;
-                    const double a1 = rv / gamma + (gv - q_.x), a2 = rw / gamma + (gw - q_.y);
-                    exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < pk_eps_nu);
+                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
+                    if (a.op.akkt_gradient == 2) exit_now = true;
+                    else {
+                        const dbl2 q_ = *Lq;
+                        const bool top = a.op.akkt_gradient == 1;       // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
+                        const double b1 = top ? (iteration >= 1 ? 0.0 : gv) : gv - q_.x;
+                        const double b2 = top ? (iteration >= 1 ? 0.0 : gw) : gw - q_.y;
+                        const double a1 = rv / gamma + b1, a2 = rw / gamma + b2;
+                        exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < pk_eps_nu);
+                    }
                 }
                 if (exit_now) {
                     f_done = true;
@@ -361,11 +391,12 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             // ---------------------------------------------------------------- the inner solver returned
             if (f_done) {
                 f_done = false;
-                inner_status = num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS;
+                inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
+                                         : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
                 inner_total += num_iter;
                 pk_last_fpr = norm_r; pk_last_cost = cost;
                 uv = hv; uw = hw;                                        // PANOC returns the feasible half step
-                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw);
+                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
                 if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
                 else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
             }
@@ -430,11 +461,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 pw = fma(-tau, dw, fma(-omt_, rw, uw));                                \
                 NMPC_HALF_STEP(pv, pw);                                                \
                 lhs = NMPC_FBE(pv, pw);                                                \
-                rejected = __any(lhs > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS;    \
+                const bool bad_ = __any(lhs > rhs_ls);                                 \
+                rejected = bad_ && ls_n < MAX_LINESEARCH_ITERATIONS;                   \
+                exhausted = bad_ && !rejected && a.op.ls_failure == 1;                 \
                 if (rejected) { tau /= 2.0; ls_n++; }                                  \
             } while (0)
             double lhs = 0.0;
-            bool rejected = false;
+            bool rejected = false, exhausted = false;
 
             if (state == D_INIT) {
                 n_grad += 2;
@@ -475,11 +508,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                             dv = rv; dw = rw;                            // empty buffer: d = r
                             rhs_ls = NMPC_FBE(uv, uw) - pk_sigma * nr2;
                             tau = 1.0; ls_n = 0;
+                            if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
                             f_trials = true;
                         }
                     } else {
                         lb_first = n_first; lb_head = n_head; lb_active = n_active; pk_H0 = n_H0;      // commit
                         if (n_take_old) { *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw}; }
+                        if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
                         NMPC_TAKE_TRIAL(psiB, src1);                     // tau = 1
                         if (rejected) NMPC_TAKE_TRIAL(psiC, src2);       // tau = 1/2
                         if (rejected) f_trials = true;
@@ -492,7 +527,17 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 if (rejected) NMPC_TAKE_TRIAL(psiB, src1);
                 if (rejected) NMPC_TAKE_TRIAL(psiC, src2);
                 if (rejected) f_trials = true;
+                else if (exhausted) f_fb = true;
                 else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+            } else if (state == D_FB) {
+                // psi, grad psi at u_bar: the plain forward-backward step (as in iteration 0)
+                n_grad++;
+                uv = hv; uw = hw;
+                cost = psiA;
+                NMPC_FETCH_GRAD(src0, gv, gw);
+                NMPC_HALF_STEP(uv, uw);
+                fbe_ok = false;
+                f_end = true;
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
@@ -507,7 +552,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 const bool crit2 = a.n2 == 0 || __any(pk_f2_norm_plus <= a.op.delta_tolerance + SMALL);
                 const bool crit3 = __any(pk_eps_nu <= a.op.tolerance + SMALL);
                 if (crit1 && crit2 && crit3) {
-                    final_status = inner_status; running = false;
+                    final_status = a.op.inner_status == 1 ? NMPC_CONVERGED : inner_status; running = false;
                 } else {
                     const bool stall = nu == 0 || __any(pk_dy_norm_plus <= a.op.sufficient_decrease * pk_dy_norm + SMALL &&
                                                         pk_f2_norm_plus <= a.op.sufficient_decrease * pk_f2_norm + SMALL);
@@ -517,6 +562,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                     pk_dy_norm = pk_dy_norm_plus; pk_f2_norm = pk_f2_norm_plus;
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
+                    else if (timed_out) { final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; running = false; nu--; }      // (the report adds the one back)
                     else if (a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min &&
                              __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.B &&
                              __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -

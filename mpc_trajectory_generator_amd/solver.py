@@ -66,6 +66,17 @@ class BatchSolver:
             pass
 
     @property
+    def variant(self) -> dict:
+        """The restatement switches in force, by name, plus the iteration budget."""
+        v = {k: names[getattr(self.opts, k)] for k, names in _lib.VARIANT_FIELDS.items()}
+        v["max_total_inner"] = int(self.opts.max_total_inner)
+        return v
+
+    def oracle_opts(self) -> dict:
+        """This handle's options as keyword arguments of the test oracle (field names are shared)."""
+        return {name: getattr(self.opts, name) for name, _ in self.opts._fields_ if name != "reserved"}
+
+    @property
     def kernel_name(self) -> str:
         """Name of the solve kernel this handle launches (diagnostic; what a kernel trace shows)."""
         return self.lib.nmpc_kernel_name(self._h).decode()

@@ -20,7 +20,9 @@ class OrcOpts(C.Structure):
                 ("delta_tolerance", C.c_double), ("initial_penalty", C.c_double),
                 ("penalty_update", C.c_double), ("tolerance_update", C.c_double),
                 ("sufficient_decrease", C.c_double), ("lbfgs_memory", C.c_int32),
-                ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("reserved", C.c_int32)]
+                ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("max_total_inner", C.c_int32),
+                ("akkt_gradient", C.c_int32), ("ls_failure", C.c_int32), ("inner_status", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class OrcStatus(C.Structure):

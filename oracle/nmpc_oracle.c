@@ -200,6 +200,10 @@ void orc_default_opts(orc_opts *o)
     o->lbfgs_memory = 10;
     o->max_inner = 500;
     o->max_outer = 10;
+    o->max_total_inner = 0;
+    o->akkt_gradient = 0;
+    o->ls_failure = 0;
+    o->inner_status = 0;
     o->reserved = 0;
 }
 
@@ -496,10 +500,12 @@ typedef struct {
 
 typedef struct {
     hvec g, gs, uh, r, d, up, gprev;   /* gradient, gradient step, half step, gamma*fpr, direction, u_plus */
+    hvec gk;                           /* gradient at the current iterate, kept through the line search (ls_failure = 1) */
     double cost, L, gamma, sigma, nr2, norm_r, tau;
     int iteration;
     lbfgs_t lb;
     uint32_t n_cost, n_grad;
+    eval_out scratch;
 } panoc_t;
 
 static void project_U(const inst_t *I, hvec *x)
@@ -575,7 +581,7 @@ static void lbfgs_apply(const inst_t *I, const lbfgs_t *lb, hvec *q)
 /* forward-backward envelope at the point whose cost/gradient/gs/uh are in the cache */
 static double fbe(const inst_t *I, const panoc_t *c)
 {
-    double t[MAXP];
+    double t[MAXP] = {0.0};
     for (int j = 0; j < I->P; ++j) {
         const double a = c->gs.v[j] - c->uh.v[j], b = c->gs.w[j] - c->uh.w[j];
         t[j] = fma(a, a, b * b);
@@ -592,12 +598,15 @@ static void do_eval(const inst_t *I, panoc_t *c, const hvec *x, double pen, cons
     if (want_grad) c->n_grad++; else c->n_cost++;
 }
 
-/* returns exit status (0 converged / 1 iterations); u in/out; iters and norm_fpr reported */
-static int panoc_solve(const inst_t *I, panoc_t *c, hvec *u, double pen, const hvec *y, double tol,
-                       double akkt_tol, int max_iter, uint32_t *iters, double *cost_out)
+/* returns exit status (0 converged / 1 iterations / 2 out of budget); u in/out; iters and norm_fpr reported.
+ * budget_left: PANOC iterations this inner solve may still spend (0 = unlimited), opts->max_total_inner. */
+static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *u, double pen, const hvec *y,
+                       double tol, double akkt_tol, int max_iter, uint32_t budget_left, uint32_t *iters,
+                       double *cost_out)
 {
     const int P = I->P, N = I->N;
-    eval_out *o = (eval_out *)malloc(sizeof(eval_out));
+    eval_out *o = &c->scratch;
+    int timed_out = 0;
     /* ---- init ---- */
     lbfgs_reset(&c->lb);
     c->iteration = 0;
@@ -631,10 +640,19 @@ static int panoc_solve(const inst_t *I, panoc_t *c, hvec *u, double pen, const h
         /* step(): returns "continue" */
         compute_fpr(I, c, u);
         if (c->norm_r < tol) {           /* fpr test, then the AKKT test (short-circuit) */
+            if (opts->akkt_gradient == 2) break;                 /* no AKKT test */
             double t[MAXP];
             for (int j = 0; j < P; ++j) {
-                const double a = c->r.v[j] / c->gamma + (c->g.v[j] - c->gprev.v[j]);
-                const double b = c->r.w[j] / c->gamma + (c->g.w[j] - c->gprev.w[j]);
+                double a, b;
+                if (opts->akkt_gradient == 1) {
+                    /* grad_prev was copied from grad at the top of this step (iteration >= 1: the
+                     * difference is exactly zero) or is still the zero vector (iteration 0) */
+                    a = c->r.v[j] / c->gamma + (c->iteration >= 1 ? 0.0 : c->g.v[j]);
+                    b = c->r.w[j] / c->gamma + (c->iteration >= 1 ? 0.0 : c->g.w[j]);
+                } else {
+                    a = c->r.v[j] / c->gamma + (c->g.v[j] - c->gprev.v[j]);
+                    b = c->r.w[j] / c->gamma + (c->g.w[j] - c->gprev.w[j]);
+                }
                 t[j] = fma(a, a, b * b);
             }
             if (sqrt(tree_sum_p(t, P)) < akkt_tol) break;
@@ -667,6 +685,8 @@ static int panoc_solve(const inst_t *I, panoc_t *c, hvec *u, double pen, const h
             grad_and_half_step(I, c, u);
         } else {
             const double rhs_ls = fbe(I, c) - c->sigma * c->nr2;
+            int exhausted = 0;
+            c->gk = c->g;
             c->tau = 1.0;
             for (int n = 0;; ++n) {
                 const double omt = 1.0 - c->tau;
@@ -674,27 +694,39 @@ static int panoc_solve(const inst_t *I, panoc_t *c, hvec *u, double pen, const h
                     c->up.v[j] = fma(-c->tau, c->d.v[j], fma(-omt, c->r.v[j], u->v[j]));
                     c->up.w[j] = fma(-c->tau, c->d.w[j], fma(-omt, c->r.w[j], u->w[j]));
                 }
-                c->gprev = c->g;                 /* cache_previous_gradient (iteration >= 1) */
+                c->gprev = c->g;                 /* akkt_gradient = 0: cached before every overwrite */
                 do_eval(I, c, &c->up, pen, y, 1, o);
                 c->cost = o->psi;
                 c->g = o->g;
                 grad_and_half_step(I, c, &c->up);
                 if (!(fbe(I, c) > rhs_ls)) break;
-                if (n >= MAX_LINESEARCH_ITERATIONS) break;
+                if (n >= MAX_LINESEARCH_ITERATIONS) { exhausted = opts->ls_failure == 1; break; }
                 c->tau /= 2.0;
             }
-            *u = c->up;
+            if (exhausted) {
+                /* tau = 0: u+ = u_bar, the forward-backward step from the current iterate */
+                c->tau = 0.0;
+                c->g = c->gk;
+                grad_and_half_step(I, c, u);
+                *u = c->uh;
+                do_eval(I, c, u, pen, y, 1, o);
+                c->cost = o->psi;
+                c->g = o->g;
+                grad_and_half_step(I, c, u);
+            } else {
+                *u = c->up;
+            }
         }
         c->iteration++;
         /* OpEn: while step() && num_iter < max_iter { num_iter++ } */
         if (!(num_iter < (uint32_t)max_iter)) break;
         num_iter++;
+        if (budget_left > 0 && num_iter >= budget_left) { timed_out = 1; break; }
     }
-    const int status = num_iter < (uint32_t)max_iter ? 0 : 1;
+    const int status = timed_out ? 2 : (num_iter < (uint32_t)max_iter ? 0 : 1);
     *iters = num_iter;
     *cost_out = c->cost;
     *u = c->uh;      /* the feasible half step is what PANOC returns */
-    free(o);
     return status;
 }
 
@@ -718,7 +750,7 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
     const int N = pb->N;
     inst_t *I = (inst_t *)malloc(sizeof(inst_t));
     panoc_t *pc = (panoc_t *)calloc(1, sizeof(panoc_t));
-    eval_out *o = (eval_out *)malloc(sizeof(eval_out));
+    eval_out *o = &pc->scratch;
     prepare(pb, p, I);
     const int P = I->P, n2 = pb->nobs + pb->ndyn;
     pc->lb.m = opts->lbfgs_memory;
@@ -741,10 +773,13 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
             y.w[t] = clampd(y.w[t], -1e12, 1e12);
         }
         uint32_t it = 0;
-        int inner_status = panoc_solve(I, pc, &u, c, &y, opts->tolerance, eps_nu, opts->max_inner, &it, &last_cost);
+        const uint32_t budget = opts->max_total_inner > 0 ? (uint32_t)opts->max_total_inner : 0u;
+        if (opts->akkt_gradient == 1) memset(&pc->gprev, 0, sizeof(pc->gprev));
+        int inner_status = panoc_solve(I, opts, pc, &u, c, &y, opts->tolerance, eps_nu, opts->max_inner,
+                                       budget ? budget - inner_total : 0u, &it, &last_cost);
         inner_total += it;
         last_fpr = pc->norm_r;
-        if (!vec_finite(&u, N)) { exit_status = 4; break; }
+        if (!vec_finite(&u, N) || !isfinite(last_cost) || !isfinite(last_fpr)) { exit_status = 4; break; }
         /* F1, F2 at the inner solution; y+ = y + c (F1 - Pi_C(F1 + y/max(c,1))) */
         eval_psi(I, &u, c, &y, 0, o);
         pc->n_cost++;
@@ -770,7 +805,7 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
         const int crit1 = nu > 0 && dy_norm_plus <= c * opts->delta_tolerance + SMALL;
         const int crit2 = n2 == 0 || f2_norm_plus <= opts->delta_tolerance + SMALL;
         const int crit3 = eps_nu <= opts->tolerance + SMALL;
-        if (crit1 && crit2 && crit3) { exit_status = inner_status; break; }
+        if (crit1 && crit2 && crit3) { exit_status = opts->inner_status == 1 ? 0 : inner_status; break; }
         const int stall = nu == 0 || (dy_norm_plus <= opts->sufficient_decrease * dy_norm + SMALL &&
                                       f2_norm_plus <= opts->sufficient_decrease * f2_norm + SMALL);
         if (!stall) c *= opts->penalty_update;
@@ -779,6 +814,7 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
         dy_norm = dy_norm_plus;
         f2_norm = f2_norm_plus;
         if (nu == opts->max_outer - 1) exit_status = 1;
+        else if (inner_status == 2) { exit_status = 2; break; }     /* the budget is spent: no further outer iteration */
     }
     store_hvec(&u, u_io, N, 1);
     store_hvec(&yplus, y_out, N, 0);
@@ -797,13 +833,14 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
         st->cost = last_cost;
         st->solve_time_ms = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
     }
-    free(o); free(pc); free(I);
+    free(pc); free(I);
     return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
-    const orc_problem *pb; const orc_opts *opts; int B, tid, nth;
+    const orc_problem *pb; const orc_opts *opts; int B;
+    int *next;                   /* shared work queue: the batch is heavy-tailed, threads pull the next instance */
     const double *p; double *u; const double *y0; const double *c0; double *y_out; orc_status *st;
     int rc;
 } job_t;
@@ -812,7 +849,9 @@ static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     const int nu = orc_n_u(j->pb), np = orc_n_p(j->pb), n1 = orc_n1(j->pb);
-    for (int b = j->tid; b < j->B; b += j->nth) {
+    for (;;) {
+        const int b = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (b >= j->B) break;
         int rc = orc_solve(j->pb, j->opts, j->p + (size_t)b * np, j->u + (size_t)b * nu,
                            j->y0 ? j->y0 + (size_t)b * n1 : NULL, j->c0 ? j->c0[b] : 0.0,
                            j->y_out ? j->y_out + (size_t)b * n1 : NULL, j->st ? j->st + b : NULL);
@@ -828,8 +867,9 @@ int orc_solve_batch(const orc_problem *pb, const orc_opts *opts, int B, const do
     if (threads > 256) threads = 256;
     pthread_t th[256];
     job_t jobs[256];
+    int next = 0;
     for (int i = 0; i < threads; ++i) {
-        jobs[i] = (job_t){pb, opts, B, i, threads, p, u, y0, c0, y_out, st, 0};
+        jobs[i] = (job_t){pb, opts, B, &next, p, u, y0, c0, y_out, st, 0};
         if (threads == 1) worker(&jobs[i]);
         else pthread_create(&th[i], NULL, worker, &jobs[i]);
     }

@@ -46,6 +46,21 @@ typedef struct orc_opts {
     int32_t lbfgs_memory;      /* m              10   */
     int32_t max_inner;         /*                500  */
     int32_t max_outer;         /*                10   */
+    int32_t max_total_inner;   /* 0 = off.  Deterministic stand-in for max_duration (mpc_generator.py:9,186):
+                                  the solve stops once this many PANOC iterations have been spent in total and
+                                  reports NotConvergedOutOfTime with the feasible half step                    */
+    /* restatement switches: choices of the OpEn restatement that cannot be verified here (DESIGN.md
+     * section 9); 0 is what round 1 shipped and what every figure is quoted for unless stated        */
+    int32_t akkt_gradient;     /* AKKT residual ||r/gamma + grad - grad_prev||: grad_prev is
+                                  0 the gradient before the last overwrite (cached before EVERY line-search
+                                    trial, carried across the inner solves of one call)
+                                  1 cached once at the top of step(), before the exit test, from iteration 1 on
+                                    and zero at iteration 0 (residual = ||r||/gamma from iteration 1 on)
+                                  2 no AKKT test: PANOC stops on ||r|| < epsilon alone                          */
+    int32_t ls_failure;        /* all 11 line-search trials fail: 0 the last one is taken anyway,
+                                  1 tau = 0: plain forward-backward step from the current iterate             */
+    int32_t inner_status;      /* outer criteria hold: 0 report the last inner solve's status,
+                                  1 report Converged                                                          */
     int32_t reserved;
 } orc_opts;
 
@@ -81,7 +96,7 @@ int orc_eval(const orc_problem *pb, const double *p, const double *u, double c, 
 int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, double *u,
               const double *y0, double c0, double *y_out, orc_status *st);
 
-/* B independent solves on `threads` host threads (pthreads, static interleave). */
+/* B independent solves on `threads` host threads (pthreads pulling from a shared work queue). */
 int orc_solve_batch(const orc_problem *pb, const orc_opts *opts, int B, const double *p, double *u,
                     const double *y0, const double *c0, double *y_out, orc_status *st, int threads);
 

@@ -19,7 +19,7 @@ def test_header_symbols_exported():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nmpc_abi_version() == 1
+    assert lib.nmpc_abi_version() == 2
 
 
 def test_sizes_and_struct_layout():
@@ -31,10 +31,19 @@ def test_sizes_and_struct_layout():
         assert (cfg.n_u, cfg.n_p, cfg.n1, cfg.n2) == (nu, np_, n1, n2)
         assert lib.nmpc_n_u(ctypes.byref(pb)) == nu and lib.nmpc_n_p(ctypes.byref(pb)) == np_
         assert lib.nmpc_n1(ctypes.byref(pb)) == n1 and lib.nmpc_n2(ctypes.byref(pb)) == n2
-    assert ctypes.sizeof(_lib.NmpcProblem) == 72 and ctypes.sizeof(_lib.NmpcOpts) == 72
+    assert ctypes.sizeof(_lib.NmpcProblem) == 72 and ctypes.sizeof(_lib.NmpcOpts) == 88
     o = _lib.NmpcOpts()
     lib.nmpc_default_opts(ctypes.byref(o))
     assert (o.tolerance, o.lbfgs_memory, o.max_inner, o.max_outer, o.initial_penalty) == (1e-4, 10, 500, 10, 1.0)
+    # the budget is off and every restatement switch is at its round-1 value by default
+    assert (o.max_total_inner, o.akkt_gradient, o.ls_failure, o.inner_status) == (0, 0, 0, 0)
+
+
+def test_oracle_and_abi_share_option_fields():
+    """The test oracle's option struct mirrors nmpc_opts field for field (the parity tests pass one dict to both)."""
+    from oracle.binding import OrcOpts
+    assert [f for f, _ in OrcOpts._fields_] == [f for f, _ in _lib.NmpcOpts._fields_]
+    assert ctypes.sizeof(OrcOpts) == ctypes.sizeof(_lib.NmpcOpts)
 
 
 def test_no_device_fails_loudly():

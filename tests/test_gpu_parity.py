@@ -124,19 +124,15 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
 
 
 @pytest.mark.parametrize("name,env,kernel", [("cfg1", {}, "nmpc_solve_hyb_kernel<ShapeDefault>"),
-                                             ("cfg1", {"NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeDefault>"),
                                              ("cfg1", {"NMPC_LAYOUT": "dual"}, "nmpc_solve_dual_kernel"),
                                              ("cfg1", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
-                                             ("cfg1", {"NMPC_SHAPE": "any", "NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeAny>"),
                                              ("cfg3", {}, "nmpc_solve_hyb_kernel<ShapeNobs50>"),
                                              ("cfg3", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
-                                             ("cfg3", {"NMPC_LAYOUT": "tri"}, "nmpc_solve_tri_kernel<ShapeNobs50>"),
                                              ("cfg2", {}, "nmpc_solve_kernel<64, ShapeN40>"),
                                              ("cfg2", {"NMPC_SHAPE": "any"}, "nmpc_solve_kernel<64>")])
 def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
-    """Shapes with a specialised three-point kernel: the run-time-shape kernel, the all-tri-layout kernel
-    and the two-point kernel (used for 20 < N_hor <= 32) must give the same bits on them; the handle
-    reports which kernel runs."""
+    """Shapes with a specialised kernel: the run-time-shape kernel and the two-point kernel (used for
+    20 < N_hor <= 32) must give the same bits on them; the handle reports which kernel runs."""
     from mpc_trajectory_generator_amd.solver import BatchSolver
     cfg = named_config(name)
     P = synthetic_batch(cfg, 11, 40, 4242, synthetic_circles=(name == "cfg3"))
@@ -146,6 +142,63 @@ def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
     try:
         assert s.kernel_name == kernel
         assert_same_solution(s.solve(P), oracle_for(cfg).solve_batch(P, threads=8))
+    finally:
+        s.close()
+
+
+# restatement switches (include/nmpc_solver.h): every value of every switch, alone and
+# combined, in every solve kernel -- hybrid (N <= 20), dual (20 < N <= 32), one-point (N > 32)
+SWITCHES = [dict(akkt_gradient=1), dict(akkt_gradient=2), dict(ls_failure=1), dict(inner_status=1),
+            dict(akkt_gradient=1, ls_failure=1, inner_status=1), dict(max_total_inner=150),
+            dict(max_total_inner=700, ls_failure=1, akkt_gradient=1)]
+
+
+@pytest.mark.parametrize("opts", SWITCHES, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+@pytest.mark.parametrize("N", [20, 24, 40])
+def test_restatement_switches_bit_exact(N, opts):
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = load_config(N_hor=N)
+    P = synthetic_batch(cfg, 11, 48 if N == 20 else 16, 777 + N)
+    s = BatchSolver(cfg, max_batch=64, **opts)
+    try:
+        assert s.variant["akkt_gradient"] == ("per_trial", "step_top", "off")[opts.get("akkt_gradient", 0)]
+        gpu = s.solve(P)
+        cpu = oracle_for(cfg, **s.oracle_opts()).solve_batch(P, threads=8)
+        assert_same_solution(gpu, cpu)
+        if "max_total_inner" in opts:       # the deterministic max_duration: NotConvergedOutOfTime, never more than the budget
+            assert gpu[2]["num_inner_iterations"].max() <= opts["max_total_inner"]
+            assert (gpu[2]["exit_status"] == 2).any()
+            assert np.all(np.isfinite(gpu[0]))
+        if opts.get("inner_status") == 1:   # outer criteria met -> Converged: f2 and dy/c within delta on all of those
+            ok = gpu[2]["exit_status"] == 0
+            assert np.all(gpu[2]["f2_norm"][ok] <= 1e-4 + 1e-12)
+    finally:
+        s.close()
+
+
+def test_line_search_exhaustion_paths_are_exercised():
+    """ls_failure only matters when all 11 trials fail; make sure the batch used above really gets there
+    (the oracle counts differ between the two settings), so the bit-exact test covers the tau = 0 branch."""
+    cfg = named_config("cfg1")
+    P = synthetic_batch(cfg, 11, 48, 797)
+    a = oracle_for(cfg).solve_batch(P, threads=8)[2]
+    b = oracle_for(cfg, ls_failure=1).solve_batch(P, threads=8)[2]
+    assert not np.array_equal(a["num_grad_evals"], b["num_grad_evals"])
+
+
+@pytest.mark.parametrize("m", [1, 5])
+@pytest.mark.parametrize("N", [20, 24, 40])
+def test_short_lbfgs_memory_bit_exact(N, m):
+    """lbfgs_memory < 10: the general (ring-buffer) two-loop code of every kernel, and no LDS write past the
+    ring (the zero column of the hybrid kernel is per allocated slot)."""
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = load_config(N_hor=N)
+    P = synthetic_batch(cfg, 11, 24, 31 * m + N)
+    s = BatchSolver(cfg, max_batch=32, lbfgs_memory=m)
+    try:
+        assert_same_solution(s.solve(P), oracle_for(cfg, lbfgs_memory=m).solve_batch(P, threads=8))
     finally:
         s.close()
 
