@@ -131,7 +131,11 @@ __global__ __launch_bounds__(64) void nmpc_loop_assemble_kernel(LoopArgs a)
             } else if (a.t == 0) {
                 v = din[e];                                    // padding block as initialised
             } else {
-                v = st < N - s ? din[e + 5 * s] : din[e];      // rotate left by s stages; the tail keeps its values
+                // the reference rotates the WHOLE flat list left by 5 s entries (path_generator.py:312): a shift by s
+                // stages inside a block, and a block's last s stages take the next block's first s (the last block's
+                // take block 0's, so a padding slot can inherit stale ellipses of obstacle 0 when 0 < K < Ndynobs)
+                const int src = e + 5 * s;
+                v = din[src < tot ? src : src - tot];
             }
             dout[e] = v;
             pd[e] = v;

@@ -106,21 +106,26 @@ class OptimizerTcpManager:
         p = np.asarray(p, dtype=np.float64).reshape(-1)
         if p.size != s.n_p:
             return SolverResponse(SolverError(3003, f"wrong number of parameters: provided {p.size}, expected {s.n_p}"))
+        # validate everything first: an error response must leave the server's warm-start state untouched
+        g = yy = None
         if initial_guess is not None:
             g = np.asarray(initial_guess, dtype=np.float64).reshape(-1)
             if g.size != s.n_u:
                 return SolverResponse(SolverError(1600, f"initial guess has incompatible dimensions: provided {g.size}, expected {s.n_u}"))
-            self._u[0] = g
         if initial_y is not None:
             yy = np.asarray(initial_y, dtype=np.float64).reshape(-1)
             if yy.size != s.n1:
                 return SolverResponse(SolverError(1700, f"wrong dimension of Lagrange multipliers: provided {yy.size}, expected {s.n1}"))
-            self._y[0] = yy
+        u_in, y_in = self._u.copy(), self._y.copy()
+        if g is not None:
+            u_in[0] = g
+        if yy is not None:
+            y_in[0] = yy
         elif not self._keep_y:
-            self._y[0] = 0.0
+            y_in[0] = 0.0
         c0 = None if initial_penalty is None else np.array([float(initial_penalty)])
         try:
-            u, y, st = s.solve(p[None, :], u0=self._u, y0=self._y, c0=c0)
+            u, y, st = s.solve(p[None, :], u0=u_in, y0=y_in, c0=c0)
         except _SolverError as e:
             return SolverResponse(SolverError(2000, f"problem solution failed: {e.message}"))
         if int(st["exit_status"][0]) == 4:

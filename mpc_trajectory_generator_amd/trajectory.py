@@ -290,7 +290,11 @@ class VectorizedRecedingHorizon:
             if self.t == 0:
                 self.dyn[:, :self.K] = self._predict(0.0, N)
             else:
-                self.dyn[:, :, :N - s] = self.dyn[:, :, s:].copy()
+                # the reference rotates the WHOLE flat list left by ndynobs * s entries (:312): inside a block that is a
+                # shift by s stages, and a block's last s stages take the next block's first s (the last block's take
+                # block 0's -- a padding slot can so inherit stale ellipses of obstacle 0 when 0 < K < Ndynobs)
+                flat = self.dyn.reshape(B, -1)
+                self.dyn = np.roll(flat, -cfg.ndynobs * s, axis=1).reshape(self.dyn.shape)
                 self.dyn[:, :self.K, N - s:] = self._predict((self.t + N - s) * cfg.ts, s)
         # closest reference sample in the sliding window (:320-325)
         lb = np.maximum(0, self.idx - s)

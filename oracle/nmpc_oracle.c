@@ -505,6 +505,7 @@ typedef struct {
     int iteration;
     lbfgs_t lb;
     uint32_t n_cost, n_grad;
+    uint32_t passes3, passes6;         /* diagnostic: evaluation passes a 3- / 6-points-per-pass schedule would need */
     eval_out scratch;
 } panoc_t;
 
@@ -633,6 +634,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
     c->gamma = GAMMA_L_COEFF / dmax(c->L, MIN_LIPSCHITZ_CONSTANT);
     c->sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * c->gamma);
     grad_and_half_step(I, c, u);
+    c->passes3++; c->passes6++;       /* u and u + h in one pass */
 
     /* ---- iterations ---- */
     uint32_t num_iter = 0;
@@ -660,6 +662,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         /* Lipschitz / gamma backtracking */
         do_eval(I, c, &c->uh, pen, y, 0, o);
         double cost_uh = o->psi;
+        int n_back = 0, n_trials = 0;
         for (int it = 0; it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && c->L < MAX_LIPSCHITZ_CONSTANT; ++it) {
             const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - hdot(&c->g, &c->r, P)
                              + (GAMMA_L_COEFF / (2.0 * c->gamma)) * c->nr2;
@@ -671,6 +674,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
             do_eval(I, c, &c->uh, pen, y, 0, o);
             cost_uh = o->psi;
             compute_fpr(I, c, u);
+            n_back++;
         }
         c->sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * c->gamma);
         /* L-BFGS buffer update and direction */
@@ -695,6 +699,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
                     c->up.w[j] = fma(-c->tau, c->d.w[j], fma(-omt, c->r.w[j], u->w[j]));
                 }
                 c->gprev = c->g;                 /* akkt_gradient = 0: cached before every overwrite */
+                n_trials++;
                 do_eval(I, c, &c->up, pen, y, 1, o);
                 c->cost = o->psi;
                 c->g = o->g;
@@ -716,6 +721,12 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
             } else {
                 *u = c->up;
             }
+        }
+        {   /* diagnostic pass model: the first pass of an iteration holds u_bar and the first k - 1 trials; every
+             * Lipschitz back-off costs a pass of its own (and a pass for the trials that were thrown away) */
+            const int first3 = n_back ? 0 : 2, first6 = n_back ? 0 : 5;
+            c->passes3 += 1 + n_back + (n_trials > first3 ? (n_trials - first3 + 2) / 3 : 0);
+            c->passes6 += 1 + n_back + (n_trials > first6 ? (n_trials - first6 + 5) / 6 : 0);
         }
         c->iteration++;
         /* OpEn: while step() && num_iter < max_iter { num_iter++ } */
@@ -783,6 +794,7 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
         /* F1, F2 at the inner solution; y+ = y + c (F1 - Pi_C(F1 + y/max(c,1))) */
         eval_psi(I, &u, c, &y, 0, o);
         pc->n_cost++;
+        pc->passes3++; pc->passes6++;
         {
             double t[MAXP];
             const double cbar_inv = 1.0 / dmax(c, 1.0);
@@ -825,7 +837,8 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
         st->num_inner_iterations = inner_total;
         st->num_cost_evals = pc->n_cost;
         st->num_grad_evals = pc->n_grad;
-        st->reserved = 0;
+        st->reserved = pc->passes3;
+        if (getenv("ORC_PASSES")) fprintf(stderr, "ORC_PASSES %p %u %u %u\n", (const void *)p, inner_total, pc->passes3, pc->passes6);
         st->last_problem_norm_fpr = last_fpr;
         st->delta_y_norm_over_c = dy_norm_plus / c;
         st->f2_norm = f2_norm_plus;

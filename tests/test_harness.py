@@ -146,10 +146,12 @@ def test_synthetic_batch_is_deterministic_and_well_formed():
     assert C.shape == (8, 550) and np.all(C[:, 40:190].reshape(8, 50, 3)[:, :, 2] == 0.5)
 
 
-@pytest.mark.parametrize("sinus", [False, True])
-def test_vectorized_receding_horizon_equals_loop_version(sinus):
+@pytest.mark.parametrize("sinus,K", [(False, 3), (True, 3), (False, 2), (False, 1)])
+def test_vectorized_receding_horizon_equals_loop_version(sinus, K):
     """NumPy-vectorised batch assembly == the per-robot loops, bit for bit, incl. per-robot dynamic
-    obstacles (linear and sinusoidal law), num_steps_taken = 2 and the braking zone."""
+    obstacles (linear and sinusoidal law), num_steps_taken = 2 and the braking zone.  K < Ndynobs moving
+    obstacles: the reference rotates the whole flat dynamic list (src/path_generator.py:312), so padding slots
+    inherit stale ellipses of obstacle 0 -- both versions must reproduce that."""
     from conftest import oracle_for
     from mpc_trajectory_generator_amd.trajectory import VectorizedRecedingHorizon
     cfg = named_config("cfg4")
@@ -161,7 +163,7 @@ def test_vectorized_receding_horizon_equals_loop_version(sinus):
     for i in [0, 3, n - 25, n - 8, n - 2, 40]:
         starts.append((route.x_ref[i] + rng.normal(0, 0.05), route.y_ref[i] + rng.normal(0, 0.05), route.theta_ref[i]))
         lists.append([[list(rng.uniform(0, 20, 2)), list(rng.uniform(0, 20, 2)), rng.uniform(0.05, 0.1),
-                       rng.uniform(0.3, 1), rng.uniform(0.3, 1), rng.uniform(0, 3)] for _ in range(3)])
+                       rng.uniform(0.3, 1), rng.uniform(0.3, 1), rng.uniform(0, 3)] for _ in range(K)])
     B = len(starts)
     loop = BatchedRecedingHorizon(route, starts, lists, sinus_object=sinus)
     for b in range(B):                                              # start the window search where the robot is
@@ -172,11 +174,15 @@ def test_vectorized_receding_horizon_equals_loop_version(sinus):
     vec = VectorizedRecedingHorizon(route, starts, dyn, sinus_object=sinus)
     vec.idx = np.array(loop.idx)
     solve = lambda P, U, Y: o.solve_batch(P, u0=U, y0=Y, threads=4)         # noqa: E731
+    stale = False
     for k in range(6):
         Pl, _ = loop.step(solve)
         Pv, _ = vec.step(solve)
         assert np.array_equal(Pl, Pv), (k, np.argwhere(Pl != Pv)[:5])
+        pad = Pl[:, 70:370].reshape(B, 3, 20, 5)[:, K:]
+        stale |= bool(pad.size and np.any(pad[..., 0:2] != 0.0))
     assert np.array_equal(vec.state, np.array([s[-3:] for s in loop.states]))
+    assert stale == (K < 3)          # the quirk is really exercised: a padding slot picked up obstacle 0's ellipses
 
 
 def test_report_counterparts():
