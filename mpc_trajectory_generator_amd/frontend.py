@@ -200,25 +200,30 @@ class VisibilityPlanner:
                              self.dyn_obs_list, sinus_object)
 
 
-# scene data of the reference's maps used by the benchmark configurations
-# (src/visibility/graphs.py:34-43 scene 1, :161-170 scene 11): boundary + obstacle polygons
-SCENE_POLYGONS = {
-    1: dict(boundary=[(0.0, 0.0), (20.0, 0.0), (20.0, 20.0), (0.0, 20.0)],
-            obstacles=[[(5.0, 0.0), (5.0, 15.0), (7.0, 15.0), (7.0, 0.0)],
-                       [(12.0, 12.5), (12.0, 20.0), (15.0, 20.0), (15.0, 12.5)],
-                       [(12.0, 0.0), (12.0, 7.5), (15.0, 7.5), (15.0, 0.0)]]),
-    11: dict(boundary=[(1.5, 1.0), (1.7, 58.6), (59.0, 58.4), (58.6, 1.3)],
-             obstacles=[[(27.0, 6.0), (27.0, 33.0), (4.0, 33.0), (4.0, 6.0)],
-                        [(65.0, 6.0), (28.1, 6.0), (28.1, 33.0), (65.0, 33.0)],
-                        [(4.4, 34.1), (44.0, 34.1), (44.0, 39.3), (55.3, 39.6), (55.3, 42.8), (44.0, 42.3),
-                         (44.1, 49.1), (54.9, 49.2), (54.9, 53.0), (4.7, 53.0)],
-                        [(47.7, 36.2), (47.7, 34.6), (57.8, 34.5), (57.8, 36.3)]]),
-}
+# scene data of the reference's 13 maps (src/visibility/graphs.py:21-191): boundary, obstacle polygons, default
+# start / end poses and dynamic-obstacle lists -- a table of coordinates (scenes.json beside this file, written by
+# tests/golden/make_scene_fixtures.py)
+def _load_scenes():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes.json")) as fh:
+        raw = json.load(fh)
+    out = {}
+    for g in raw:
+        out[g["index"]] = dict(boundary=[tuple(p) for p in g["boundary"]],
+                               obstacles=[[tuple(p) for p in o] for o in g["obstacles"]],
+                               start=tuple(g["start"]), end=tuple(g["end"]),
+                               dyn_obs_list=[[tuple(o[0]), tuple(o[1])] + list(o[2:]) for o in g["dyn_obs_list"]])
+    return out
+
+
+SCENE_POLYGONS = _load_scenes()
 
 
 def scene_planner(cfg: Config, scene: int) -> VisibilityPlanner:
+    """Planner on scene 0..12 of the reference (``Graphs().get_graph(complexity)``, graphs.py:199-203)."""
     s = SCENE_POLYGONS[scene]
-    return VisibilityPlanner(cfg, s["boundary"], s["obstacles"])
+    return VisibilityPlanner(cfg, s["boundary"], s["obstacles"], s["dyn_obs_list"])
 
 
 def random_routes(cfg: Config, scene: int, n: int, seed: int, min_length: float = 12.0):

@@ -74,44 +74,52 @@ class TrajectoryGenerator:
         params_per_dyn_obs = cfg.N_hor * cfg.ndynobs
         limit = 500.0 / cfg.ts if max_steps is None else max_steps
         t_temp = time.time()
-        while (not terminal) and t < limit:                                   # :290
-            t_overhead = time.time()
-            x_init = states[-cfg.nx:]                                         # :293
-            if len(route.vertices):                                           # :295-304
-                constraints = harness.static_constraints(route, (x_init[0], x_init[1]))
-            if t == 0:                                                        # :306-309
-                for i, obs in enumerate(harness.dyn_obstacle(cfg, route.dyn_obs_list, t * cfg.ts, cfg.N_hor,
-                                                             self.sinus_object)):
-                    dyn_constraints[i * params_per_dyn_obs:(i + 1) * params_per_dyn_obs] = \
-                        [float(v) for tup in obs for v in tup]
-            else:                                                             # :310-316 rotate left, refresh the tail
-                k = cfg.ndynobs * cfg.num_steps_taken
-                dyn_constraints = dyn_constraints[k:] + dyn_constraints[:k]
-                for i, obs in enumerate(harness.dyn_obstacle(cfg, route.dyn_obs_list,
-                                                             (t + cfg.N_hor - cfg.num_steps_taken) * cfg.ts,
-                                                             cfg.num_steps_taken, self.sinus_object)):
-                    dyn_constraints[(i + 1) * params_per_dyn_obs - k:(i + 1) * params_per_dyn_obs] = \
-                        [float(v) for tup in obs for v in tup]
-            lb_idx = max(0, idx - 1 * cfg.num_steps_taken)                    # :320-325
-            ub_idx = min(len(x_ref), idx + 5 * cfg.num_steps_taken)
-            idx = harness.closest_index((x_init[0], x_init[1]), route.ref_points[lb_idx:ub_idx]) + lb_idx
-            last_u = system_input[-cfg.nu:] if len(system_input) else [0.0] * cfg.nu     # :371-374
-            parameters = harness.assemble_params(route, x_init, last_u, idx, constraints, dyn_constraints)
-            if record_parameters is not None:
-                record_parameters.append(list(parameters))
-            try:                                                              # :384-391
-                exit_status, solver_time = mpc_step(cfg, parameters, mng, cfg.num_steps_taken, system_input, states)
-                self.solver_times.append(solver_time)
-            except RuntimeError as err:
-                if self.verbose:
-                    print(err)
-                return None
-            if exit_status in cfg.bad_exit_codes and self.verbose:            # :393-394
-                print(f"[MPC] Bad converge status: {exit_status}")
-            if np.allclose(states[-3:-1], end[0:2], atol=0.05, rtol=0) and abs(system_input[-2]) < 0.005:   # :397
-                terminal = True
-            t += cfg.num_steps_taken
-            self.overhead_times.append((time.time() - t_overhead) * 1000.0 - solver_time)
+        try:
+            while (not terminal) and t < limit:                                   # :290
+                t_overhead = time.time()
+                x_init = states[-cfg.nx:]                                         # :293
+                if len(route.vertices):                                           # :295-304
+                    constraints = harness.static_constraints(route, (x_init[0], x_init[1]))
+                if t == 0:                                                        # :306-309
+                    for i, obs in enumerate(harness.dyn_obstacle(cfg, route.dyn_obs_list, t * cfg.ts, cfg.N_hor,
+                                                                 self.sinus_object)):
+                        dyn_constraints[i * params_per_dyn_obs:(i + 1) * params_per_dyn_obs] = \
+                            [float(v) for tup in obs for v in tup]
+                else:                                                             # :310-316 rotate left, refresh the tail
+                    k = cfg.ndynobs * cfg.num_steps_taken
+                    dyn_constraints = dyn_constraints[k:] + dyn_constraints[:k]
+                    for i, obs in enumerate(harness.dyn_obstacle(cfg, route.dyn_obs_list,
+                                                                 (t + cfg.N_hor - cfg.num_steps_taken) * cfg.ts,
+                                                                 cfg.num_steps_taken, self.sinus_object)):
+                        dyn_constraints[(i + 1) * params_per_dyn_obs - k:(i + 1) * params_per_dyn_obs] = \
+                            [float(v) for tup in obs for v in tup]
+                lb_idx = max(0, idx - 1 * cfg.num_steps_taken)                    # :320-325
+                ub_idx = min(len(x_ref), idx + 5 * cfg.num_steps_taken)
+                idx = harness.closest_index((x_init[0], x_init[1]), route.ref_points[lb_idx:ub_idx]) + lb_idx
+                last_u = system_input[-cfg.nu:] if len(system_input) else [0.0] * cfg.nu     # :371-374
+                parameters = harness.assemble_params(route, x_init, last_u, idx, constraints, dyn_constraints)
+                if record_parameters is not None:
+                    record_parameters.append(list(parameters))
+                try:                                                              # :384-391
+                    exit_status, solver_time = mpc_step(cfg, parameters, mng, cfg.num_steps_taken, system_input, states)
+                    self.solver_times.append(solver_time)
+                except RuntimeError as err:
+                    if self.verbose:
+                        print(err)
+                    return None
+                if exit_status in cfg.bad_exit_codes and self.verbose:            # :393-394
+                    print(f"[MPC] Bad converge status: {exit_status}")
+                if np.allclose(states[-3:-1], end[0:2], atol=0.05, rtol=0) and abs(system_input[-2]) < 0.005:   # :397
+                    terminal = True
+                t += cfg.num_steps_taken
+                self.overhead_times.append((time.time() - t_overhead) * 1000.0 - solver_time)
+        except KeyboardInterrupt:                                             # :405-415: kill the server, return what was driven so far
+            if self.verbose:
+                print("[MPC] killing TCP connection to MCP solver...")
+            mng.kill()
+            nx = cfg.nx
+            return (states[0::nx], states[1::nx], system_input[0::2], system_input[1::2],
+                    self.solver_times, self.overhead_times)
         mng.kill()                                                            # :417
         self.time_dict["mpc_time"] = int(1000 * (time.time() - t_temp))
         self.time_dict["solver_time"] = sum(self.solver_times)

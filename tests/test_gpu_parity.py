@@ -264,29 +264,6 @@ def test_edge_cases(solvers):
         s.solve(np.zeros((2, cfg.n_p - 1)))
 
 
-def test_full_size_batch_properties(solvers):
-    """BASELINE config 1 at full size (B = 8192): size-independent properties + sampled oracle parity."""
-    cfg = named_config("cfg1")
-    s, o = solvers("cfg1"), oracle_for(cfg)
-    P = synthetic_batch(cfg, 11, 8192, 0)
-    u, y, st = s.solve(P)
-    assert np.all(np.isfinite(u))
-    assert u[:, 0::2].min() >= cfg.lin_vel_min and u[:, 0::2].max() <= cfg.lin_vel_max
-    assert np.abs(u[:, 1::2]).max() <= cfg.ang_vel_max
-    conv = st["exit_status"] == 0
-    assert np.all(st["f2_norm"][conv] <= 1e-4 + 1e-12) and np.all(st["delta_y_norm_over_c"][conv] <= 1e-4 + 1e-12)
-    # permutation invariance: an instance's result does not depend on its slot / wave-mate
-    perm = np.random.default_rng(0).permutation(8192)
-    u2, y2, st2 = s.solve(P[perm])
-    assert np.array_equal(u2, u[perm]) and np.array_equal(st2["num_inner_iterations"], st["num_inner_iterations"][perm])
-    # sampled oracle parity
-    idx = np.random.default_rng(1).choice(8192, 64, replace=False)
-    uo, yo, sto = o.solve_batch(P[idx], threads=8)
-    assert np.array_equal(u[idx], uo) and np.array_equal(y[idx], yo)
-    for f in STATUS_FIELDS:
-        assert np.array_equal(st[f][idx], sto[f]), f
-
-
 def test_tcp_shim_sequential_semantics():
     """OptimizerTcpManager-shaped handle: warm start carried by the manager, OpEn error codes."""
     from mpc_trajectory_generator_amd.tcp_shim import OptimizerTcpManager

@@ -35,6 +35,7 @@ class ReplayManager:
         class S:
             pass
         if self.k >= len(self.solutions):
+            self.interrupted = True
             raise KeyboardInterrupt
         s = S()
         s.solution = [float(v) for v in self.solutions[self.k]]
@@ -100,14 +101,19 @@ def test_driver_replays_reference_parameter_sequence(name, over, sinus):
     rec = []
     mng = ReplayManager(d["solutions"], d["exit"])
     gen = TrajectoryGenerator(cfg, sinus_object=sinus, manager_factory=lambda: mng)
-    try:
-        out = gen.run(route, record_parameters=rec)
-    except KeyboardInterrupt:
-        out = None
+    out = gen.run(route, record_parameters=rec)
     P = np.array(rec[:len(d["params"])])
     assert P.shape == d["params"].shape
     assert np.array_equal(P, d["params"])
-    if out is not None:                                   # scene 1 runs to the goal
+    if getattr(mng, "interrupted", False):
+        # the recording ends before the goal: the replay raises KeyboardInterrupt inside the loop, which the driver must
+        # answer like the reference (src/path_generator.py:405-415): kill the server, return the partial trajectory
+        assert not mng.alive and out is not None
+        xx, xy, uv, uw = out[:4]
+        n_calls = len(d["solutions"])
+        assert len(uv) == len(uw) == n_calls * cfg.num_steps_taken and len(xx) == len(xy) == len(uv) + 1
+        assert np.array_equal(uv[:cfg.num_steps_taken], d["solutions"][0][0:2 * cfg.num_steps_taken:2])
+    else:                                                 # scene 1 runs to the goal
         xx, xy, uv, uw = out[:4]
         assert np.array_equal(xx, d["xx"]) and np.array_equal(xy, d["xy"])
         assert np.array_equal(uv, d["uv"]) and np.array_equal(uw, d["uw"])
