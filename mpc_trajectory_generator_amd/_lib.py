@@ -124,7 +124,7 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = build_library()
+    path = os.environ.get("NMPC_LIB_PATH") or build_library()      # (NMPC_LIB_PATH: instrumented builds, scripts/ only)
     lib = C.CDLL(path)
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     lib.nmpc_default_opts.argtypes = [C.POINTER(NmpcOpts)]
