@@ -177,7 +177,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); F2_k left in the LDS slice
+// psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); WRITE_F2: F2_k also left in the LDS slice
 // ---------------------------------------------------------------------------------------------
 #ifdef NMPC_PROFILE
 #define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_evt[i] += t_ - nmpc_evl; nmpc_evl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -187,7 +187,7 @@ __device__ long long nmpc_dummy_;
 #else
 #define NMPC_EVTICK(i) do { } while (0)
 #endif
-template <int P, class SH = ShapeAny>
+template <int P, class SH = ShapeAny, bool WRITE_F2 = false>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
@@ -297,33 +297,32 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const double fsum = group_sum<P>(acc, lane);
     NMPC_EVTICK(2);     // accelerations, ALM term, cost sum
 
-    // obstacle penalties on the post-update state (:106-119).  F2_k = sum_t max(0, h_kt); an obstacle
-    // that no stage of either instance in this wave touches contributes exactly 0 and is skipped
-    // (wave-uniform branch); its bit in `act` stays clear so the adjoint sweep skips it too.
+    // obstacle penalties on the post-update state (:106-119).  F2_k = sum_t max(0, h_kt); an obstacle that no stage
+    // of any query point in this wave is inside of contributes exactly 0 to psi and to grad psi and is skipped
+    // (wave-uniform branch).  The adjoint terms of a touched obstacle, c F2_k dh_kt/d(x, y), are added right where
+    // its F2_k has just been summed -- same operations in the same order as a separate sweep would do them (cross-
+    // track term first, circles in ascending order, then ellipses), without the round trip of F2 through LDS.
     double pen = 0.0;
     unsigned long long act = 0ull;      // wave-uniform: circles some stage is inside of
     unsigned act_dyn = 0u;              // wave-uniform: ellipses some stage is inside of
-    unsigned m_lo = 0u, m_hi = 0u, m_dy = 0u;       // per lane: which circles / ellipses THIS stage is inside of
+    double dyh[NDYN_MAX];
     {
         const lds_double *ob = L + a.map.obs;
         const int nobs4 = (nobs + 3) & ~3;
 #pragma unroll SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1
-        for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, VALU only
+        for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, one ballot each
             double od[12];
 #pragma unroll
             for (int f = 0; f < 12; ++f) od[f] = ob[f];
             __builtin_amdgcn_sched_barrier(0);
-            unsigned bits = 0u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
                 const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
-                bits |= (in_r && h > 0.0 ? 1u : 0u) << j;
+                if (__any(in_r && h > 0.0)) act |= 1ull << (k + j);
             }
-            if (k < 32) m_lo |= bits << k; else m_hi |= bits << (k - 32);
         }
         NMPC_EVTICK(5);     // static circle scan
-        double dyh[NDYN_MAX];
         {
             double dv_[NDYN_MAX][DY_FIELDS];
 #pragma unroll
@@ -341,53 +340,16 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                     const double eb = fma(dx, sa, -(dy * ca));
                     const double h = fma(-(eb * eb), dv_[k][DY_IRY2], fma(-(ea * ea), dv_[k][DY_IRX2], 1.0));   // (:118)
                     dyh[k] = in ? fmax(h, 0.0) : 0.0;
-                    m_dy |= (in_r && dyh[k] > 0.0 ? 1u : 0u) << k;
+                    if (__any(in_r && dyh[k] > 0.0)) act_dyn |= 1u << k;
                 }
             }
         }
         NMPC_EVTICK(6);     // ellipse scan
-        // F2_k = sum_t max(0, h_kt).  An obstacle no stage in this wave is inside of contributes exactly 0
-        // and is skipped; typically nothing is touched and the whole block is one uniform branch.
-        if (__any((m_lo | m_hi | m_dy) != 0u)) {
-            const unsigned u_lo = wave_or(m_lo), u_hi = nobs > 32 ? wave_or(m_hi) : 0u;
-            act = ((unsigned long long)u_hi << 32) | u_lo;
-            act_dyn = ndyn > 0 ? wave_or(m_dy) : 0u;
-            for (unsigned long long rem = act; rem;) {      // two touched circles per trip: their tree sums interleave
-                const int k0 = __builtin_ctzll(rem);
-                rem &= rem - 1;
-                const bool two = rem != 0ull;
-                const int k1 = two ? __builtin_ctzll(rem) : k0;
-                rem &= rem - (two ? 1ull : 0ull);
-                const lds_double *o0 = L + a.map.obs + 3 * k0, *o1 = L + a.map.obs + 3 * k1;
-                const double ax = o0[0], ay = o0[1], ar = o0[2], bx = o1[0], by = o1[1], br = o1[2];
-                const double dx0 = xn - ax, dy0 = yn - ay, dx1 = xn - bx, dy1 = yn - by;
-                const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar)), h1 = fma(-dy1, dy1, fma(-dx1, dx1, br));
-                const double f20 = group_sum<P>(in ? fmax(h0, 0.0) : 0.0, lane);
-                const double f21 = group_sum<P>(in ? fmax(h1, 0.0) : 0.0, lane);
-                if (t == 0) { L[f2off + k0] = f20; if (two) L[f2off + k1] = f21; }
-                pen = fma(f20, f20, pen);
-                if (two) pen = fma(f21, f21, pen);
-            }
-#pragma unroll
-            for (int k = 0; k < NDYN_MAX; ++k) {
-                if (act_dyn & (1u << k)) {
-                    const double f2 = group_sum<P>(dyh[k], lane);
-                    if (t == 0) L[f2off + nobs + k] = f2;
-                    pen = fma(f2, f2, pen);
-                }
-            }
-        }
     }
-    psi = fma(half_c, pen, fsum);
-    pen_out = pen;
-    NMPC_EVTICK(3);     // obstacles
-    if (!want_grad) return;
-    NMPC_WAVE_SYNC();          // F2_k written by lane 0 of the group are read by all its lanes below
-
-    // ---- adjoint sweep (what CasADi reverse AD generated for the reference) ----
-    double gx, gy;
-    {
-        const lds_double *sg = L + a.map.seg + SEG_STRIDE * bi;          // arg-min segment of this stage
+    // ---- adjoint, first term: the cross-track error through the arg-min segment of this stage ----
+    double gx = 0.0, gy = 0.0;
+    if (want_grad) {
+        const lds_double *sg = L + a.map.seg + SEG_STRIDE * bi;
         const double px = xn - sg[0], py = yn - sg[1];
         const double dot = fma(px, sg[2], py * sg[3]);
         const double that = dot * sg[4];
@@ -399,37 +361,60 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         gx = two_q * fma(m, sg[2], -ex);
         gy = two_q * fma(m, sg[3], -ey);
     }
-    {
-        const lds_double *f2 = L + f2off;
-        while (act) {                                        // only the circles some stage is inside of
-            const int k = __builtin_ctzll(act);
-            act &= act - 1;
-            const lds_double *ob = L + a.map.obs + 3 * k;
-            const double wk = -2.0 * (c * f2[k]);
-            const double dx = xn - ob[0], dy = yn - ob[1];
-            const double h = fma(-dy, dy, fma(-dx, dx, ob[2]));
-            if (h > 0.0) { gx = fma(wk, dx, gx); gy = fma(wk, dy, gy); }
+    // ---- touched obstacles: F2_k, its square into the penalty, its adjoint terms ----
+    if ((act | act_dyn) != 0ull) {
+        for (unsigned long long rem = act; rem;) {          // two touched circles per trip: their tree sums interleave
+            const int k0 = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            const bool two = rem != 0ull;
+            const int k1 = two ? __builtin_ctzll(rem) : k0;
+            rem &= rem - (two ? 1ull : 0ull);
+            const lds_double *o0 = L + a.map.obs + 3 * k0, *o1 = L + a.map.obs + 3 * k1;
+            const double ax = o0[0], ay = o0[1], ar = o0[2], bx = o1[0], by = o1[1], br = o1[2];
+            const double dx0 = xn - ax, dy0 = yn - ay, dx1 = xn - bx, dy1 = yn - by;
+            const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar)), h1 = fma(-dy1, dy1, fma(-dx1, dx1, br));
+            const double f20 = group_sum<P>(in ? fmax(h0, 0.0) : 0.0, lane);
+            const double f21 = group_sum<P>(in ? fmax(h1, 0.0) : 0.0, lane);
+            if (WRITE_F2 && t == 0) { L[f2off + k0] = f20; if (two) L[f2off + k1] = f21; }
+            pen = fma(f20, f20, pen);
+            if (two) pen = fma(f21, f21, pen);
+            if (want_grad) {
+                const double w0 = -2.0 * (c * f20), w1 = -2.0 * (c * f21);
+                if (h0 > 0.0) { gx = fma(w0, dx0, gx); gy = fma(w0, dy0, gy); }
+                if (two && h1 > 0.0) { gx = fma(w1, dx1, gx); gy = fma(w1, dy1, gy); }
+            }
         }
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
             if (act_dyn & (1u << k)) {
-                const double wk = -2.0 * (c * f2[nobs + k]);
-                const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
-                const double irx2 = dyn.get(k, DY_IRX2), iry2 = dyn.get(k, DY_IRY2);
-                const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
-                const double ea = fma(dx, ca, dy * sa);
-                const double eb = fma(dx, sa, -(dy * ca));
-                const double h = fma(-(eb * eb), iry2, fma(-(ea * ea), irx2, 1.0));
-                if (h > 0.0) {
-                    const double A = ea * irx2, Bq = eb * iry2;
-                    const double hx = fma(A, ca, Bq * sa);
-                    const double hy = fma(A, sa, -(Bq * ca));
-                    gx = fma(wk, hx, gx);
-                    gy = fma(wk, hy, gy);
+                const double f2 = group_sum<P>(dyh[k], lane);
+                if (WRITE_F2 && t == 0) L[f2off + nobs + k] = f2;
+                pen = fma(f2, f2, pen);
+                if (want_grad) {
+                    const double wk = -2.0 * (c * f2);
+                    const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
+                    const double irx2 = dyn.get(k, DY_IRX2), iry2 = dyn.get(k, DY_IRY2);
+                    const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
+                    const double ea = fma(dx, ca, dy * sa);
+                    const double eb = fma(dx, sa, -(dy * ca));
+                    const double h = fma(-(eb * eb), iry2, fma(-(ea * ea), irx2, 1.0));
+                    if (h > 0.0) {
+                        const double A = ea * irx2, Bq = eb * iry2;
+                        const double hx = fma(A, ca, Bq * sa);
+                        const double hy = fma(A, sa, -(Bq * ca));
+                        gx = fma(wk, hx, gx);
+                        gy = fma(wk, hy, gy);
+                    }
                 }
             }
         }
     }
+    psi = fma(half_c, pen, fsum);
+    pen_out = pen;
+    NMPC_EVTICK(3);     // obstacles
+    if (!want_grad) return;
+
+    // ---- adjoint sweep, continued (what CasADi reverse AD generated for the reference) ----
     // the post-update state of stage t is the tracked state of stage t+1 (:86) or the terminal state (:148)
     const double wq = t < N - 1 ? sc[SC_Q] : sc[SC_QN];
     const double wth = t < N - 1 ? sc[SC_QTH] : sc[SC_QTHN];
@@ -489,7 +474,8 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
     for (int k = t; k < a.n2; k += P) L[a.map.f2 + k] = 0.0;
     NMPC_WAVE_SYNC();
     double psi, pen, gv, gw, av, aw;
-    eval_psi<P>(a, L, a.map.f2, lane, t, zv, zw, c, 1.0 / fmax(c, 1.0), yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
+    eval_psi<P, ShapeAny, true>(a, L, a.map.f2, lane, t, zv, zw, c, 1.0 / fmax(c, 1.0), yv, yw, vref, dyn, true, psi, pen, gv, gw, av, aw);
+    NMPC_WAVE_SYNC();          // F2_k written by lane 0 of the group are read by all its lanes below
     if (inst >= a.B) return;
     if (t == 0 && a.ev_psi) a.ev_psi[b] = psi;
     if (in) {
@@ -856,10 +842,11 @@ __host__ __device__ inline int park_stride(int N) { return 6 * N + 16; }
 // ---------------------------------------------------------------------------------------------
 namespace nmpc {
 constexpr double SCHED_CLEARANCE = 0.6;    // m
+constexpr double SCHED_GRAZE = 0.05;       // m: the reference itself touches an obstacle's edge -- its penalty will be active
 constexpr double SCHED_BEND = 0.05;        // rad, summed |heading change| of the reference samples
 constexpr double SCHED_SPEED_GAP = 1.0;    // m/s between the last applied and the first reference speed: the
                                            // acceleration bounds stay active for several stages (many outer iterations)
-constexpr int SCHED_LEVELS = 5;            // hardness level = number of criteria met, 0..4
+constexpr int SCHED_LEVELS = 9;            // hardness level = 4 x (reference grazes an obstacle) + number of the other criteria met
 
 __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
 {
@@ -868,7 +855,7 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
     const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
     const double *p = a.p + (size_t)b * a.n_p;
     const double *ps = p + NZ + N, *pd = ps + 3 * nobs, *pr = pd + 5 * ndyn * N;
-    bool hard = false;
+    bool hard = false, graze = false;
     double bend = 0.0;
     for (int t = 0; t < N; ++t) {
         const double rx = pr[3 * t], ry = pr[3 * t + 1];
@@ -880,20 +867,22 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
         for (int k = 0; k < nobs; ++k) {
             const double r = ps[3 * k + 2];
             if (r > 0.0) {
-                const double dx = rx - ps[3 * k], dy = ry - ps[3 * k + 1], lim = r + SCHED_CLEARANCE;
+                const double dx = rx - ps[3 * k], dy = ry - ps[3 * k + 1], lim = r + SCHED_CLEARANCE, lim0 = r + SCHED_GRAZE;
                 hard |= dx * dx + dy * dy < lim * lim;
+                graze |= dx * dx + dy * dy < lim0 * lim0;
             }
         }
         for (int k = 0; k < ndyn; ++k) {
             const double *e = pd + (k * N + t) * 5;
-            const double dx = rx - e[0], dy = ry - e[1], lim = fmax(e[2], e[3]) + SCHED_CLEARANCE;
+            const double dx = rx - e[0], dy = ry - e[1], lim = fmax(e[2], e[3]) + SCHED_CLEARANCE, lim0 = fmin(e[2], e[3]) + SCHED_GRAZE;
             hard |= dx * dx + dy * dy < lim * lim;
+            graze |= dx * dx + dy * dy < lim0 * lim0;
         }
     }
     const bool gap = fabs(p[NZ] - p[3]) > SCHED_SPEED_GAP;
     // the horizon reaches the goal: the reference is padded with the end pose (degenerate segments, braking profile)
     const bool goal = pr[3 * (N - 1)] == pr[3 * (N - 2)] && pr[3 * (N - 1) + 1] == pr[3 * (N - 2) + 1];
-    cls[b] = (unsigned char)((hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0) + (gap ? 1 : 0) + (goal ? 1 : 0));    // criteria met
+    cls[b] = (unsigned char)((graze ? 4 : 0) + (hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0) + (gap ? 1 : 0) + (goal ? 1 : 0));
 }
 
 // stable partition of 0..B-1 by level (highest first); one block, deterministic

@@ -9,17 +9,22 @@ from mpc_trajectory_generator_amd.harness import synthetic_batch
 from mpc_trajectory_generator_amd.frontend import random_routes
 cfg = named_config("cfg1")
 sol = BatchSolver(cfg, max_batch=8192)
-P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=1000))
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+P = synthetic_batch(cfg, 11, 8192, seed, routes=random_routes(cfg, 11, 32, seed=1000 + seed))
 sol.solve(P)
 u, y, st = sol.solve(P)
 ps = st["reserved"].astype(np.int64); cyc = st["last_problem_norm_fpr"]; slot = st["f2_norm"].astype(int)
 print("kernel ms", st["solve_time_ms"][0], "slots", np.bincount(slot))
-end = (st["cost"] - st["cost"].min()) / 100e3          # ms since the first instance finished (100 MHz clock)
+t0 = st["delta_y_norm_over_c"].min()
+end = (st["cost"] - t0) / 100e3          # ms since the first instance started (100 MHz clock)
+first = (st["delta_y_norm_over_c"] - t0) / 100e3
+moves = st["penalty"].astype(int)
 last = np.argsort(-end)[:10]
-print("  last to finish:", [(int(b), int(ps[b]), int(slot[b]), round(float(end[b]), 1)) for b in last], "(inst, passes, slot, ms)")
+print("  last to finish:", [(int(b), int(ps[b]), int(slot[b]), round(float(first[b]), 1), int(moves[b]), round(float(end[b]), 1)) for b in last], "(inst, passes, slot, first start ms, migrations, end ms)")
+print("  start time of instances > 6000 passes: pctl", np.percentile(first[ps > 6000], [0, 50, 90, 100]).round(1), " migrations hist", np.bincount(moves[ps > 6000]))
 top = np.argsort(-ps)[:12]
 for b in top:
-    print(f"  inst {b}: passes {ps[b]} slot {slot[b]} {cyc[b]/2.4e3/ps[b]:.2f} us/pass, finished at {end[b]:.1f} ms")
+    print(f"  inst {b}: passes {ps[b]} final slot {slot[b]}, first started {first[b]:.1f} ms, migrations {moves[b]}, last leg {cyc[b]/2.4e6:.1f} ms, finished at {end[b]:.1f} ms -> {1e3*(end[b]-first[b])/ps[b]:.2f} us/pass overall")
 for s_ in (0, 1):
     m = (slot == s_) & (ps > 3000)
     print(f"  slot {s_}: instances>3000 passes: {m.sum()}, mean us/pass {np.mean(cyc[m]/2.4e3/ps[m]):.2f}")
