@@ -87,6 +87,11 @@ typedef __attribute__((address_space(3))) double lds_double;
 typedef double dbl2 __attribute__((ext_vector_type(2)));     // (v, w) pair, 16-byte aligned
 typedef __attribute__((address_space(3))) dbl2 lds_double2;
 
+#ifdef NMPC_NO_SCHED_BARRIER
+#define NMPC_SCHED_BARRIER() do { } while (0)
+#else
+#define NMPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
 #define NMPC_WAVE_SYNC()                                           \
     do {                                                           \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     \
@@ -251,7 +256,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int f = 0; f < 5; ++f) nxt[j][f] = sg[j * SEG_STRIDE + f];
-            __builtin_amdgcn_sched_barrier(0);
+            NMPC_SCHED_BARRIER();
             double d2[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -267,7 +272,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                 bi = d2[j] < best ? i + j : bi;
                 best = fmin(best, d2[j]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -314,7 +319,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             double od[12];
 #pragma unroll
             for (int f = 0; f < 12; ++f) od[f] = ob[f];
-            __builtin_amdgcn_sched_barrier(0);
+            NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
@@ -329,7 +334,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             for (int k = 0; k < NDYN_MAX; ++k)
 #pragma unroll
                 for (int f = 0; f < DY_FIELDS; ++f) dv_[k][f] = k < ndyn ? dyn.get(k, f) : 0.0;
-            __builtin_amdgcn_sched_barrier(0);
+            NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int k = 0; k < NDYN_MAX; ++k) {
                 dyh[k] = 0.0;

@@ -36,14 +36,23 @@ __device__ __forceinline__ dbl2 ld_pair(const lds_double2 *base, int idx, bool k
     return v;
 }
 
+// two horizon sums for the price of one tree: the solver state is replicated in both 32-lane halves of the wave, so half 0
+// reduces `a`, half 1 reduces `b` (each the canonical 32-entry tree of its half) and a permlane32 swap hands both results
+// to every lane.  Same bits as two separate group_sum<32>.
+__device__ __forceinline__ void pair_sum(double a, double b, int lane, double &sum_a, double &sum_b)
+{
+    const double s = group_sum<32>((lane & 32) ? b : a, lane);
+    both_halves(s, sum_a, sum_b);
+}
+
 // forward-backward envelope at the point whose cost / gradient / gradient step / half step are given
 template <int P>
 __device__ __forceinline__ double fbe_value(double cost, double gamma, double sv, double sw, double hv, double hw,
                                             double gv, double gw, int lane)
 {
     const double e1 = sv - hv, e2 = sw - hw;
-    const double dist2 = group_sum<P>(fma(e1, e1, e2 * e2), lane);
-    const double gg = hdot<P>(gv, gw, gv, gw, lane);
+    double dist2, gg;
+    pair_sum(fma(e1, e1, e2 * e2), fma(gv, gv, gw * gw), lane, dist2, gg);
     return cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
 }
 
@@ -208,7 +217,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
                     } else {
                         const dbl2 os_ = *Los, og_ = *Log;
                         const double s1 = uv - os_.x, s2 = uw - os_.y, y1 = rv - og_.x, y2 = rw - og_.y;
-                        const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
+                        double ys, ss;
+                        pair_sum(fma(s1, y1, s2 * y2), fma(s1, s1, s2 * s2), lane, ys, ss);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
                         if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
                         if (__any(ok)) {

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #define pk_H0 Lpar[9]
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
+#define pk_gr Lpar[12]          /* <grad psi, r> of the current iterate: summed together with ||r||^2, used by the Lipschitz test */
 
 
     // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
-                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                { double gr_; pair_sum(fma(rv, rv, rw * rw), fma(gv, rv, gw * rw), lane, nr2, gr_); pk_gr = gr_; }
                 norm_r = sqrt(nr2);
                 lip_it++;
                 xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             if (f_begin) {
                 f_begin = false;
                 rv = uv - hv; rw = uw - hw;
-                nr2 = hdot<P>(rv, rw, rv, rw, lane);
+                { double gr_; pair_sum(fma(rv, rv, rw * rw), fma(gv, rv, gw * rw), lane, nr2, gr_); pk_gr = gr_; }
                 norm_r = sqrt(nr2);
                 bool exit_now = false;
                 if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                     } else {
                         const dbl2 os_ = *Los, og_ = *Log;
                         const double s1 = uv - os_.x, s2 = uw - os_.y, y1 = rv - og_.x, y2 = rw - og_.y;
-                        const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
+                        double ys, ss;
+                        pair_sum(fma(s1, y1, s2 * y2), fma(s1, s1, s2 * s2), lane, ys, ss);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
                         if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
                         if (__any(ok)) {
@@ -490,8 +492,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 // failed speculative pass; the L-BFGS buffer is empty there).  D_ITER: half 1 holds the
                 // speculative trial u+(tau = 1) on the tentative direction.
                 n_cost++;
-                const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
-                                 + pk_c_lip * nr2;
+                const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - pk_gr + pk_c_lip * nr2;
                 if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(pk_Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
                     f_back = true;                                       // (speculation discarded)
                 } else {
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #undef pk_H0
 #undef pk_sigma
 #undef pk_c_lip
+#undef pk_gr
 
 #undef NMPC_FETCH_GRAD
 #undef NMPC_TAKE_TRIAL
