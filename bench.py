@@ -325,7 +325,8 @@ def main():
         "p50_inner_iters": float(np.median(st["num_inner_iterations"])),
         "p99_inner_iters": float(np.percentile(st["num_inner_iterations"], 99)),
         "max_inner_iters": int(st["num_inner_iterations"].max()),
-        "critical_instance": {"passes": int(st["reserved"].max()), "us_per_pass_if_alone": 1e3 * kern_ms / max(int(st["reserved"].max()), 1),
+        # the batch ends with its slowest instance: its evaluation passes, and the batch time spread over them
+        "critical_instance": {"passes": int(st["reserved"].max()), "kernel_us_per_critical_pass": 1e3 * kern_ms / max(int(st["reserved"].max()), 1),
                               "mean_passes": float(st["reserved"].mean())},
         # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s);
         # the kernel issues no MFMA -- "bound_detail" says what actually limits it
@@ -341,8 +342,8 @@ def main():
                          "traffic": traffic, "bytes_per_launch": bytes_alg, "traffic_source": traffic_src},
     }
 
-    if not args.no_cpu_baseline and not args.warm:
-        # CPU leg: the oracle on the host cores, bounded sample of the same batch (rank 0, any N)
+    if not args.no_cpu_baseline and not args.warm and world == 1:
+        # CPU leg: the oracle on the host cores, bounded sample of the same batch (rank 0, N = 1 only)
         from oracle import Oracle
         orc = Oracle(cfg.N_hor, cfg.Nobs, cfg.Ndynobs, cfg.ts, cfg.lin_vel_min, cfg.lin_vel_max, cfg.ang_vel_max,
                      cfg.lin_acc_min, cfg.lin_acc_max, cfg.ang_acc_max, **solver.oracle_opts())
@@ -358,7 +359,10 @@ def main():
         same = bool(np.array_equal(uo, u_gpu[:n]) and np.array_equal(yo, y_gpu[:n])
                     and np.array_equal(sto["num_inner_iterations"], st["num_inner_iterations"][:n])
                     and np.array_equal(sto["exit_status"], st["exit_status"][:n]))
-        n1t = int(min(n, max(4, (rate / cores) * 4.0)))          # about 4 s on one thread
+        t = time.perf_counter()                                  # one thread: a short probe sizes a sample of about 5 s
+        orc.solve_batch(P_host[:16], threads=1)
+        r1 = 16 / (time.perf_counter() - t)
+        n1t = int(min(n, max(16, r1 * 5.0)))
         t = time.perf_counter()
         orc.solve_batch(P_host[:n1t], threads=1)
         dt1 = time.perf_counter() - t

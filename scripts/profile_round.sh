@@ -1,19 +1,32 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence behind bench.py's roofline numbers on the GPU box:
-#   1. kernel trace + stats of the default bench run        -> kernel_stats.csv
-#   2. PMC passes, each in its own run (no trace domains):  FETCH_SIZE | WRITE_SIZE | SQ instruction mix | SQ waits
-# usage (through gpurun):  bash scripts/profile_round.sh r01      ; results under gpurun_out/prof_<tag>/
+#   1. kernel trace + stats of the bench's timed steps          -> kernel_stats.csv   (must agree with bench's kernel_ms)
+#   2. PMC passes, each in its own run (no trace domains): FETCH_SIZE | WRITE_SIZE | SQ instruction mix | SQ waits
+#                                                              -> pmc_*.csv, traffic.json (what bench.py quotes as `traffic`)
+#   3. the same SQ passes for ONE hard instance solved alone (a single wavefront): what a pass costs without a neighbour
+#   4. the bench lines: headline, the other BASELINE configs, the iteration-budget line, the receding-horizon loop
+# usage (through gpurun):  bash scripts/profile_round.sh r02      ; results under gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipelined > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
-for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
-            "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
-            "wait:SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"; do
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 5 --warmup 1 --no-extras > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES"
+SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:$SQ1" "wait:$SQ2"; do
     name=${pass%%:*}; ctrs=${pass#*:}
     rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_one.py > "$OUT/pmc_$name.log" 2>&1
 done
+for pass in "lone_sq:$SQ1" "lone_wait:$SQ2"; do
+    name=${pass%%:*}; ctrs=${pass#*:}
+    rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_$name.log" 2>&1
+done
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.log"
+for c in cfg2 cfg3 cfg4; do python bench.py --config $c --steps 3 --warmup 1 --no-pipelined > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.log"; done
+python bench.py --config cfg3 --batch 65536 --steps 2 --warmup 1 --no-extras > "$OUT/bench_cfg3_64k.json" 2> "$OUT/bench_cfg3_64k.log"
+python bench.py --steps 5 --warmup 1 --budget 1500 --no-cpu-baseline > "$OUT/bench_budget1500.json" 2> "$OUT/bench_budget1500.log"
+NMPC_BENCH_FORCE_DIST=1 python bench.py --steps 5 --warmup 1 --no-extras > "$OUT/bench_rccl_world1.json" 2> "$OUT/bench_rccl_world1.log"
+python scripts/bench_receding.py > "$OUT/bench_receding.json" 2> "$OUT/bench_receding.log"
+python scripts/perf_probe.py $TAG > "$OUT/perf_probe.json" 2> "$OUT/perf_probe.log"
 python scripts/profile_summarise.py "$OUT"

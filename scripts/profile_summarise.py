@@ -1,10 +1,12 @@
-"""Boils the rocprofv3 output of scripts/profile_round.sh down to the small CSVs kept under profiles/."""
+"""Boils the rocprofv3 output of scripts/profile_round.sh down to the small files kept under profiles/."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, ".")
 out = sys.argv[1]
 # kernel stats: rocprofv3 writes <dir>/<host>/<pid>_kernel_stats.csv or <dir>/trace_kernel_stats.csv
 cands = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -12,7 +14,8 @@ if cands:
     rows = list(csv.reader(open(cands[0])))
     with open(os.path.join(out, "kernel_stats.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(rows)
-for name in ("fetch", "write", "sq", "wait"):
+per_kernel = {}
+for name in ("fetch", "write", "sq", "wait", "lone_sq", "lone_wait"):
     files = glob.glob(os.path.join(out, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
@@ -28,10 +31,28 @@ for name in ("fetch", "write", "sq", "wait"):
                     "Dispatches", "Counter_Value_Per_Dispatch"])
         for (k, c), (tot, n, meta) in sorted(agg.items()):
             w.writerow([k, *meta, c, n, tot / n])
+            per_kernel[(name, k, c)] = tot / n
     log = os.path.join(out, f"pmc_{name}.log")
     if os.path.exists(log):
         for line in open(log):
             if line.startswith("launches"):
                 with open(os.path.join(out, f"pmc_{name}.csv"), "a") as fh:
                     fh.write("# " + line)
+# traffic.json: HBM bytes per launch of the solve kernel = FETCH_SIZE (KiB) x 2 [gfx950: wide reads are tallied at half
+# their bytes, MI355X_MICROARCH.md section HBM] + WRITE_SIZE (KiB), keyed by kernel + source hash + workload
+from mpc_trajectory_generator_amd import _lib      # noqa: E402
+fetch = {k: v for (n, k, c), v in per_kernel.items() if n == "fetch" and c == "FETCH_SIZE" and "solve" in k}
+write = {k: v for (n, k, c), v in per_kernel.items() if n == "write" and c == "WRITE_SIZE" and "solve" in k}
+entries = []
+for k in fetch:
+    if k in write:
+        short = k.split("(")[0].replace("void ", "").replace("nmpc::", "")
+        entries.append({"kernel": short.replace("<nmpc::", "<").strip(), "source_hash": _lib.source_hash(), "config": "cfg1", "batch": 8192,
+                        "routes": 32, "fetch_size_kib": fetch[k], "write_size_kib": write[k],
+                        "hbm_bytes_per_launch": 2 * fetch[k] * 1024 + write[k] * 1024,
+                        "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of scripts/pmc_one.py (two launches of the "
+                               "headline batch); FETCH_SIZE doubled per the gfx950 wide-read correction, WRITE_SIZE as reported"})
+with open(os.path.join(out, "traffic.json"), "w") as fh:
+    json.dump(entries, fh, indent=1)
+print(json.dumps(entries))
 print(open(os.path.join(out, "bench.json")).read().strip()[:400])
