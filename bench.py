@@ -108,6 +108,9 @@ def main():
                          "multipliers (SURVEY.md section 8d second timing); the headline metric is the cold start")
     ap.add_argument("--budget", type=int, default=0,
                     help="max_total_inner: deterministic stand-in for the reference's max_duration (0 = off, the headline)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="solver option / restatement switch (include/nmpc_solver.h), e.g. --opt akkt_gradient=1 --opt ls_failure=1; "
+                         "the line then reports that variant under `solver_variant` (the headline uses the defaults)")
     args = ap.parse_args()
     if args.no_extras:
         args.no_cpu_baseline = args.no_pipelined = True
@@ -165,6 +168,9 @@ def main():
 
     P_host = make_batch(rank)                                             # timing seeds 0..R-1
     opts = {"max_total_inner": args.budget} if args.budget > 0 else {}
+    for kv in args.opt:
+        k, v = kv.split("=")
+        opts[k] = int(v)
     solver = BatchSolver(cfg, max_batch=B, device=local, **opts)
     d_p = torch.from_numpy(P_host).to(dev)
     d_u = torch.zeros(B, cfg.n_u, dtype=torch.float64, device=dev)
@@ -248,7 +254,7 @@ def main():
         stats = ts_.cpu().numpy()
 
     # ------------------------------------------------------------------ extras, all outside the timed region
-    extras_ok = not use_dist and not args.warm and not args.no_extras and args.budget == 0
+    extras_ok = not use_dist and not args.warm and not args.no_extras and args.budget == 0 and not args.opt
     seeds = warm = pipelined = None
     if extras_ok:
         # (a) seeds 1 and 2 of the same recipe: the launch-order heuristic must not be fit to seed 0
@@ -372,9 +378,16 @@ def main():
                                "single_thread": {"value": n1t / dt1, "unit": "solves/s", "sample": f"first {n1t} instances, {dt1:.1f} s"},
                                "mean_inner_iters": float(sto["num_inner_iterations"].mean()),
                                "gpu_bitwise_equal_on_sample": same}
-    print(json.dumps(out))
+    # the JSON line must be the LAST thing on stdout: tear RCCL down first and flush C stdio (RCCL prints its version
+    # banner through it, which would otherwise land after this line when stdout is a pipe or a file)
     if use_dist:
         dist.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
