@@ -85,6 +85,19 @@ def test_solve_cold_start_bit_exact(solvers, name, scene, B):
     assert_same_solution(solvers(name).solve(P), oracle_for(cfg).solve_batch(P, threads=8))
 
 
+def test_pass_model_of_the_oracle_equals_the_kernels_pass_counter(solvers):
+    """The oracle also counts how many evaluation passes a three-points-per-pass schedule needs for its (sequential)
+    run -- u and u + h together; u_bar with the first two trials; further trials three at a time; a pass per Lipschitz
+    back-off -- and the hybrid kernel counts the passes it actually executed.  Equal on every instance: the kernel
+    wastes no pass, and the 6-point figure the same model gives (helper waves) can be trusted."""
+    cfg = named_config("cfg1")
+    P = synthetic_batch(cfg, 11, 96, 4711)
+    _, _, st = solvers("cfg1").solve(P)
+    _, _, sto = oracle_for(cfg).solve_batch(P, threads=8)
+    assert np.array_equal(st["reserved"], sto["reserved"])
+    assert st["reserved"].min() >= 3 and np.all(st["reserved"] >= st["num_outer_iterations"] * 2)
+
+
 def test_solve_nobs50_and_dynamic_obstacles(solvers):
     cfg = named_config("cfg3")
     P = synthetic_batch(cfg, 11, 32, 12345, synthetic_circles=True)
