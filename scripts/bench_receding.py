@@ -25,7 +25,11 @@ ap.add_argument("--host", action="store_true")
 ap.add_argument("--split", type=int, default=2,
                 help="device loop only: split the fleet into this many sub-fleets, each with its own handle and HIP "
                      "stream, stepped alternately -- one sub-fleet's slow instances overlap the others' bulk")
+ap.add_argument("--budget", type=int, default=0,
+                help="max_total_inner per solve: the deterministic counterpart of the reference's 0.5 s max_duration "
+                     "(src/mpc/mpc_generator.py:9,186); 0 = off")
 args = ap.parse_args()
+sopts = {"max_total_inner": args.budget} if args.budget > 0 else {}
 cfg = named_config("cfg4")
 route = harness.scene_route(cfg, args.scene)
 rng = np.random.Generator(np.random.PCG64(0))
@@ -38,7 +42,7 @@ jj = np.minimum(n - 1, i0[:, None] + rng.integers(0, 30, (B, K)))
 c = np.stack([np.array(route.x_ref)[jj], np.array(route.y_ref)[jj]], axis=2)
 dyn = (c + rng.uniform(-5, 5, (B, K, 2)), c + rng.uniform(-5, 5, (B, K, 2)), rng.uniform(0.05, 0.1, (B, K)),
        rng.uniform(0.3, 1.0, (B, K)), rng.uniform(0.3, 1.0, (B, K)), rng.uniform(0, np.pi, (B, K)))
-solver = BatchSolver(cfg, max_batch=B)
+solver = BatchSolver(cfg, max_batch=B, **sopts)
 if not args.host:
     from mpc_trajectory_generator_amd.trajectory import DeviceRecedingHorizon
     import ctypes
@@ -46,7 +50,7 @@ if not args.host:
     parts = np.array_split(np.arange(B), args.split)
     loops, streams = [], []
     for ids in parts:
-        sv = solver if not loops else BatchSolver(cfg, max_batch=len(ids))
+        sv = solver if not loops else BatchSolver(cfg, max_batch=len(ids), **sopts)
         loops.append(DeviceRecedingHorizon(sv, route, starts[ids], tuple(a[ids] for a in dyn), max_steps=args.steps, idx0=i0[ids]))
         strm = ctypes.c_void_p()
         assert hip.hipStreamCreate(ctypes.byref(strm)) == 0
@@ -66,11 +70,13 @@ if not args.host:
         "metric": "nmpc_receding_horizon_solves_per_sec", "value": B * (args.steps - 1) / total, "unit": "solves/s",
         "config": {"workload": f"cfg4 smooth_velocity, scene {args.scene}, B={B}, {args.steps} receding-horizon steps, "
                                "num_steps_taken=2, warm start (u, y carried; c reset), loop entirely on device"
+                               + (f", at most {args.budget} PANOC iterations per solve (NotConvergedOutOfTime beyond)" if args.budget else "")
                                + (f", fleet split into {args.split} sub-fleets on {args.split} streams" if args.split > 1 else ""),
                    "kernel": solver.kernel_name},
         "ms_per_step": 1e3 * total / (args.steps - 1), "mean_inner_iters_first_step": float(st0["num_inner_iterations"].mean()),
         "mean_inner_iters_last_step": float(st["num_inner_iterations"].mean()),
-        "converged_frac_last_step": float((st["exit_status"] == 0).mean()), "robots_at_goal": int(done.sum())}))
+        "converged_frac_last_step": float((st["exit_status"] == 0).mean()),
+        "out_of_time_frac_last_step": float((st["exit_status"] == 2).mean()), "robots_at_goal": int(done.sum())}))
     sys.exit(0)
 rh = VectorizedRecedingHorizon(route, starts, dyn)
 rh.idx = i0.astype(np.int64)
