@@ -14,7 +14,7 @@
 //   line search      X = (u+(tau) | u+(tau/2))       Y = u+(tau/4)
 // Trials are consumed in order and the first accepted one ends the iteration, exactly as the
 // sequential line search would; evaluations past the accepted trial are discarded and not counted.
-// Same results and counters as nmpc_solve_tri.h, nmpc_solve_dual.h and the sequential oracle.
+// Same results and counters as nmpc_solve_dual.h (the two-point kernel) and the sequential oracle.
 //
 // Migration.  With two waves resident per SIMD the hardware serves the older wave slot first: measured on
 // MI355X (scripts/slot_probe.py) a pass costs 5.3 us on wave slot 0 and 6.2-7.1 us on slot 1, whatever
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         if (inst < 0) break;
 
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
-        double dbg_first = (double)__builtin_amdgcn_s_memrealtime(), dbg_moves = 0.0;      // (experiments: first start, migrations)
+        // (experiments, scripts/slot_probe.py: first start and migration count travel with the instance; parked in LDS)
+        Lpar[13] = (double)__builtin_amdgcn_s_memrealtime(); Lpar[14] = 0.0;
         if (a.dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
         DynStage dyn;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             pk_eps_nu = pks[1]; pk_dy_norm = pks[2]; pk_f2_norm = pks[3]; pk_dy_norm_plus = pks[4]; pk_f2_norm_plus = pks[5];
             pk_last_fpr = pks[6]; pk_last_cost = pks[7];
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
-            dbg_first = pks[13]; dbg_moves = pks[14] + 1.0;
+            Lpar[13] = pks[13]; Lpar[14] = pks[14] + 1.0;
         }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 ps_[0] = pen_c; ps_[1] = pk_eps_nu; ps_[2] = pk_dy_norm; ps_[3] = pk_f2_norm; ps_[4] = pk_dy_norm_plus;
                 ps_[5] = pk_f2_norm_plus; ps_[6] = pk_last_fpr; ps_[7] = pk_last_cost; ps_[8] = (double)nu;
                 ps_[9] = (double)inner_total; ps_[10] = (double)n_cost; ps_[11] = (double)n_grad; ps_[12] = (double)n_pass;
-                ps_[13] = dbg_first; ps_[14] = dbg_moves;
+                ps_[13] = Lpar[13]; ps_[14] = Lpar[14];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                 s.last_problem_norm_fpr = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
                 s.f2_norm = (double)hw_slot;
                 s.cost = (double)__builtin_amdgcn_s_memrealtime();
-                s.delta_y_norm_over_c = dbg_first; s.penalty = dbg_moves;
+                s.delta_y_norm_over_c = Lpar[13]; s.penalty = Lpar[14];
             }
 #ifdef NMPC_PROFILE
             {
