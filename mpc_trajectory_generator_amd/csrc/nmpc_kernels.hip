@@ -44,7 +44,8 @@ struct LdsMap {
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
-    int dyn;     // NDYN_MAX x 6 x P per-stage ellipse data
+    int dyn;     // NDYN_MAX x 6 x dyn_stride per-stage ellipse data
+    int dyn_stride;  // columns per (ellipse, field): 24 / 32 for the three- / two-point layouts, N rounded up to even for one point
     int vec;     // 7 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed, grad at u_k
     int rho;     // m
     int S, Y;    // m slots x N lanes x (v, w)
@@ -144,7 +145,9 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     {
         lds_double *col = L + a.map.dyn + t;
         dyn.col = col;
-        dyn.stride = lay_cols<P>();
+        // one point per wave (P = 64): only the N real stages have a column (the slice then fits 7 waves per CU, not 4)
+        const int ds = P == 64 ? a.map.dyn_stride : lay_cols<P>();
+        dyn.stride = ds;
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
             double ex = 0.0, ey = 0.0, ca = 0.0, sa = 0.0, irx2 = 1.0, iry2 = 1.0;
@@ -156,12 +159,14 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
                 iry2 = 1.0 / (e[3] * e[3]);
                 sincos_cw_t(e[4], (const lds_double *)(L + a.map.cw), sa, ca);
             }
-            col[(k * DY_FIELDS + DY_EX) * lay_cols<P>()] = ex;
-            col[(k * DY_FIELDS + DY_EY) * lay_cols<P>()] = ey;
-            col[(k * DY_FIELDS + DY_CA) * lay_cols<P>()] = ca;
-            col[(k * DY_FIELDS + DY_SA) * lay_cols<P>()] = sa;
-            col[(k * DY_FIELDS + DY_IRX2) * lay_cols<P>()] = irx2;
-            col[(k * DY_FIELDS + DY_IRY2) * lay_cols<P>()] = iry2;
+            if (P != 64 || t < ds) {
+                col[(k * DY_FIELDS + DY_EX) * ds] = ex;
+                col[(k * DY_FIELDS + DY_EY) * ds] = ey;
+                col[(k * DY_FIELDS + DY_CA) * ds] = ca;
+                col[(k * DY_FIELDS + DY_SA) * ds] = sa;
+                col[(k * DY_FIELDS + DY_IRX2) * ds] = irx2;
+                col[(k * DY_FIELDS + DY_IRY2) * ds] = iry2;
+            }
         }
     }
     const double *pr = pd + 5 * ndyn * N;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     double vref = 0.0;
     DynStage dyn;
     dyn.col = L + a.map.dyn + t;
-    dyn.stride = P;
+    dyn.stride = P == 64 ? a.map.dyn_stride : P;
     // horizon vectors: (v, w) pair per lane
     double uv = 0, uw = 0, gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0;   // u, grad, grad-step, half-step, gamma*fpr
     double dv = 0, dw = 0, pv = 0, pw = 0, qv = 0, qw = 0;                                      // direction, u_plus, previous gradient
@@ -1012,15 +1017,20 @@ static LdsMap make_map(const nmpc_problem &pb, int m, int P)
     mp.par = o; o += 16;
     mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
     mp.obs = o; o += 3 * (pb.nobs + 4);
-    mp.f2 = o;  o += 3 * (pb.nobs + pb.ndyn + 1);     // one F2 array per query point (dual / hybrid kernels)
+    const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
+    mp.f2 = o;  o += points * (pb.nobs + pb.ndyn + 1);
     mp.rho = o; o += m;
     const int cols = P == 20 ? 32 : P;                // >= nmpc::lay_cols; the hybrid kernel parks 32 state-layout columns
-    mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * cols;
+    // one point per wave keeps its solver vectors in registers and needs ellipse columns for the real stages only: without
+    // the 64-column tables a 40-stage slice is 21.9 KB instead of 32.9 KB -- 7 resident waves per CU instead of 4
+    mp.dyn_stride = P == 64 ? ((pb.N + 1) & ~1) : (P == 20 ? nmpc::lay_cols<20>() : P);
+    mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * (P == 64 ? mp.dyn_stride : cols);
     o = (o + 1) & ~1;
-    mp.vec = o; o += 7 * 2 * cols;
+    mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
     o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
-    mp.S = o;   o += 2 * (pb.N + 1) * m;        // (+1: the hybrid kernel keeps an all-zero column per slot)
-    mp.Y = o;   o += 2 * (pb.N + 1) * m;
+    const int ring = P == 20 ? pb.N + 1 : pb.N;      // (+1: the hybrid kernel keeps an all-zero column per slot)
+    mp.S = o;   o += 2 * ring * m;
+    mp.Y = o;   o += 2 * ring * m;
     mp.total = (o + 1) & ~1;
     return mp;
 }
