@@ -394,3 +394,15 @@ def test_batched_receding_horizon_on_gpu_equals_oracle(solvers):
         Pb, stb = b.step(lambda P, U, Y: o.solve_batch(P, u0=U, y0=Y, threads=8))
         assert np.array_equal(Pa, Pb) and np.array_equal(a.state, b.state)
         assert np.array_equal(sta["num_inner_iterations"], stb["num_inner_iterations"])
+
+
+def test_fuzz_shapes_and_options():
+    """scripts/fuzz_parity.py: random shapes (all three solve kernels) x random solver options and restatement switches x
+    random small batches, cold and warm-started with user penalties -- every case bit-identical to the oracle."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "32", "7"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches: 0 of 32" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
