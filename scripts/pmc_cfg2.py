@@ -1,0 +1,14 @@
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from mpc_trajectory_generator_amd import named_config
+from mpc_trajectory_generator_amd.solver import BatchSolver
+from mpc_trajectory_generator_amd.harness import synthetic_batch
+from mpc_trajectory_generator_amd.frontend import random_routes
+cfg = named_config("cfg2")
+sol = BatchSolver(cfg, max_batch=8192)
+P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=1000))
+for _ in range(2):
+    u, y, st = sol.solve(P)
+ev = (st["num_cost_evals"].astype(np.int64) + st["num_grad_evals"]).sum()
+print("launches 2 evals/launch", int(ev), "iters", int(st["num_inner_iterations"].astype(np.int64).sum()), "ms", float(st["solve_time_ms"][0]))
