@@ -856,7 +856,7 @@ constexpr double SCHED_GRAZE = 0.05;       // m: the reference itself touches an
 constexpr double SCHED_BEND = 0.05;        // rad, summed |heading change| of the reference samples
 constexpr double SCHED_SPEED_GAP = 1.0;    // m/s between the last applied and the first reference speed: the
                                            // acceleration bounds stay active for several stages (many outer iterations)
-constexpr int SCHED_LEVELS = 9;            // hardness level = 4 x (reference grazes an obstacle) + number of the other criteria met
+constexpr int SCHED_LEVELS = 13;           // hardness level = 4 x (grazes) + 4 x (grazes within the first half of the horizon) + other criteria met
 
 __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
 {
@@ -865,7 +865,7 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
     const int N = a.pb.N, nobs = a.pb.nobs, ndyn = a.pb.ndyn;
     const double *p = a.p + (size_t)b * a.n_p;
     const double *ps = p + NZ + N, *pd = ps + 3 * nobs, *pr = pd + 5 * ndyn * N;
-    bool hard = false, graze = false;
+    bool hard = false, graze = false, early = false;
     double bend = 0.0;
     for (int t = 0; t < N; ++t) {
         const double rx = pr[3 * t], ry = pr[3 * t + 1];
@@ -880,6 +880,7 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
                 const double dx = rx - ps[3 * k], dy = ry - ps[3 * k + 1], lim = r + SCHED_CLEARANCE, lim0 = r + SCHED_GRAZE;
                 hard |= dx * dx + dy * dy < lim * lim;
                 graze |= dx * dx + dy * dy < lim0 * lim0;
+                early |= 2 * t < N && dx * dx + dy * dy < lim0 * lim0;      // the sooner the robot meets the obstacle, the longer the solve
             }
         }
         for (int k = 0; k < ndyn; ++k) {
@@ -892,7 +893,7 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
     const bool gap = fabs(p[NZ] - p[3]) > SCHED_SPEED_GAP;
     // the horizon reaches the goal: the reference is padded with the end pose (degenerate segments, braking profile)
     const bool goal = pr[3 * (N - 1)] == pr[3 * (N - 2)] && pr[3 * (N - 1) + 1] == pr[3 * (N - 2) + 1];
-    cls[b] = (unsigned char)((graze ? 4 : 0) + (hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0) + (gap ? 1 : 0) + (goal ? 1 : 0));
+    cls[b] = (unsigned char)((graze ? 4 : 0) + (early ? 4 : 0) + (hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0) + (gap ? 1 : 0) + (goal ? 1 : 0));
 }
 
 // stable partition of 0..B-1 by level (highest first); one block, deterministic

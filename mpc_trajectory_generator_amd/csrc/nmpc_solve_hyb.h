@@ -133,6 +133,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
     const bool unfavoured = hw_slot != 0u;
     const int PS = park_stride(N);
 
+    // first round: the queue's head -- the instances that look hardest -- goes to the favoured wave slots; the other
+    // waves hold back until half of the resident waves have fetched (bounded: they go ahead after ~40 us regardless)
+    if (a.order && unfavoured && a.park_min > 0) {
+        const unsigned want = (unsigned)(a.B < 2 * (int)gridDim.x ? a.B / 2 : (int)gridDim.x / 2);
+        for (int spin = 0; spin < 400; ++spin) {
+            if (__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+
     for (;;) {
         // ------------------------------------------------------------------ next instance: parked long-runners first
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
