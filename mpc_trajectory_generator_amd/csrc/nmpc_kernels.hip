@@ -120,6 +120,43 @@ template <class SH> __device__ __forceinline__ int shape_N(const KArgs &a) { if 
 template <class SH> __device__ __forceinline__ int shape_nobs(const KArgs &a) { if constexpr (SH::NOBS >= 0) return SH::NOBS; else return a.pb.nobs; }
 template <class SH> __device__ __forceinline__ int shape_ndyn(const KArgs &a) { if constexpr (SH::NDYN >= 0) return SH::NDYN; else return a.pb.ndyn; }
 
+// The LDS slice layout (offsets in doubles) as a function of the problem shape and the lane layout P (20: three query points
+// per wave, 32: two, 64: one).  constexpr: the shape-specialised kernels fold every offset into the ds_* instructions'
+// immediate fields instead of carrying a dozen kernel arguments in (spilled) SGPRs; the host computes the same map for the
+// run-time-shape kernels and for sizing the launch.  The L-BFGS ring is sized for MAXMEM slots whatever opts.lbfgs_memory is.
+__host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P)
+{
+    LdsMap mp{};
+    int o = 0;
+    mp.sc = o;  o += 20;
+    mp.cw = o;  o += CW_NCOEF;
+    mp.par = o; o += 16;
+    mp.seg = o; o += SEG_STRIDE * (N + 5);
+    mp.obs = o; o += 3 * (nobs + 4);
+    const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
+    mp.f2 = o;  o += points * (nobs + ndyn + 1);
+    mp.rho = o; o += MAXMEM;
+    const int cols = P == 20 ? 32 : P;                // >= lay_cols; the hybrid kernel parks 32 state-layout columns
+    // one point per wave keeps its solver vectors in registers and needs ellipse columns for the real stages only: without
+    // the 64-column tables a 40-stage slice is 21.6 KB instead of 32.9 KB -- 7 resident waves per CU instead of 4
+    mp.dyn_stride = P == 64 ? ((N + 1) & ~1) : (P == 20 ? 24 : P);
+    mp.dyn = o; o += NDYN_MAX * 6 * (P == 64 ? mp.dyn_stride : cols);
+    o = (o + 1) & ~1;
+    mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
+    o = (o + 1) & ~1;                                 // 16-byte alignment for the double2 arrays
+    const int ring = P == 20 ? N + 1 : N;             // (+1: the hybrid kernel keeps an all-zero column per slot)
+    mp.S = o;   o += 2 * ring * MAXMEM;
+    mp.Y = o;   o += 2 * ring * MAXMEM;
+    mp.total = (o + 1) & ~1;
+    return mp;
+}
+// the map a kernel instantiation works with: compile-time for a fixed shape, the launch argument otherwise
+template <class SH, int P> __device__ __forceinline__ LdsMap the_map(const KArgs &a)
+{
+    if constexpr (SH::N > 0 && SH::NOBS >= 0 && SH::NDYN >= 0) return lds_layout(SH::N, SH::NOBS, SH::NDYN, P);
+    else return a.map;
+}
+
 // ---------------------------------------------------------------------------------------------
 // instance set-up: p -> LDS slice + per-lane registers     (reference mpc_generator.py:73-79,93-104,127-136)
 // ---------------------------------------------------------------------------------------------
@@ -128,25 +165,26 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
                                                  double &vref, DynStage &dyn)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
-    if (t < 8) L[a.map.sc + t] = p[t];                      // state, last input, target (p[8:10] unused)
-    if (t >= 8 && t < 18) L[a.map.sc + t] = p[t + 2];       // ten weights p[10:20]
-    if (t < CW_NCOEF) L[a.map.cw + t] = CW_COEF_DEV[t];
+    const LdsMap mp = the_map<SH, P>(a);
+    if (t < 8) L[mp.sc + t] = p[t];                      // state, last input, target (p[8:10] unused)
+    if (t >= 8 && t < 18) L[mp.sc + t] = p[t + 2];       // ten weights p[10:20]
+    if (t < CW_NCOEF) L[mp.cw + t] = CW_COEF_DEV[t];
     NMPC_WAVE_SYNC();
     vref = t < N ? p[NZ + t] : 0.0;
     const double *ps = p + NZ + N;
     for (int k = t; k < ((nobs + 3) & ~3); k += P) {       // padded to a multiple of 4 with inert zero circles
         const bool real = k < nobs;
         const double r = real ? ps[3 * k + 2] : 0.0;
-        L[a.map.obs + 3 * k] = real ? ps[3 * k] : 0.0;
-        L[a.map.obs + 3 * k + 1] = real ? ps[3 * k + 1] : 0.0;
-        L[a.map.obs + 3 * k + 2] = r * r;
+        L[mp.obs + 3 * k] = real ? ps[3 * k] : 0.0;
+        L[mp.obs + 3 * k + 1] = real ? ps[3 * k + 1] : 0.0;
+        L[mp.obs + 3 * k + 2] = r * r;
     }
     const double *pd = ps + 3 * nobs;
     {
-        lds_double *col = L + a.map.dyn + t;
+        lds_double *col = L + mp.dyn + t;
         dyn.col = col;
         // one point per wave (P = 64): only the N real stages have a column (the slice then fits 7 waves per CU, not 4)
-        const int ds = P == 64 ? a.map.dyn_stride : lay_cols<P>();
+        const int ds = P == 64 ? mp.dyn_stride : lay_cols<P>();
         dyn.stride = ds;
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
@@ -157,7 +195,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
                 ey = e[1];
                 irx2 = 1.0 / (e[2] * e[2]);
                 iry2 = 1.0 / (e[3] * e[3]);
-                sincos_cw_t(e[4], (const lds_double *)(L + a.map.cw), sa, ca);
+                sincos_cw_t(e[4], (const lds_double *)(L + mp.cw), sa, ca);
             }
             if (P != 64 || t < ds) {
                 col[(k * DY_FIELDS + DY_EX) * ds] = ex;
@@ -176,7 +214,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
         const double ax = pr[3 * i], ay = pr[3 * i + 1];
         const double bx = pr[3 * i + 3], by = pr[3 * i + 4];
         const double dx = bx - ax, dy = by - ay;
-        lds_double *sg = L + a.map.seg + SEG_STRIDE * t;
+        lds_double *sg = L + mp.seg + SEG_STRIDE * t;
         sg[0] = ax;
         sg[1] = ay;
         sg[2] = dx;
@@ -204,6 +242,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                                          double &gw, double &av_out, double &aw_out)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
+    const LdsMap mp = the_map<SH, P>(a);
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
     // every stage lane of the tri layout is inside a 20-stage horizon; lanes 60..63 then hold
     // don't-care values that no cross-lane operation lets into the other lanes (nmpc_device.h)
@@ -215,7 +254,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     long long *nmpc_evt = nmpc_prof_lds + 4096 + (threadIdx.x == 0 ? 0 : 8);   // lane 0 accumulates; others to a dummy row
     long long nmpc_evl = __builtin_amdgcn_s_memtime();
 #endif
-    const lds_double *sc = L + a.map.sc;
+    const lds_double *sc = L + mp.sc;
     const double x0 = sc[SC_X0], y0 = sc[SC_Y0], th0 = sc[SC_TH0];
     const double xf = sc[SC_XF], yf = sc[SC_YF], thf = sc[SC_THF];
 
@@ -223,7 +262,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const double thn = fma(ts, group_prefix<P>(zw, lane), th0);
     const double th = from_prev<P>(thn, lane, th0);
     double sn, cs;
-    sincos_cw_t(th, (const lds_double *)(L + a.map.cw), sn, cs);
+    sincos_cw_t(th, (const lds_double *)(L + mp.cw), sn, cs);
     const double xn = fma(ts, group_prefix<P>(zv * cs, lane), x0);
     const double yn = fma(ts, group_prefix<P>(zv * sn, lane), y0);
     const double xp = from_prev<P>(xn, lane, x0);
@@ -245,7 +284,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     double best = __builtin_inf();
     int bi = 0;
     {
-        const lds_double *sg = L + a.map.seg;
+        const lds_double *sg = L + mp.seg;
         const int nseg4 = (N - 1 + 3) & ~3;
         // software pipeline: the ten LDS reads of the NEXT pair of segments are issued before the current
         // pair is reduced (the scheduling barriers keep the compiler from sinking them to their uses)
@@ -317,7 +356,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     unsigned act_dyn = 0u;              // wave-uniform: ellipses some stage is inside of
     double dyh[NDYN_MAX];
     {
-        const lds_double *ob = L + a.map.obs;
+        const lds_double *ob = L + mp.obs;
         const int nobs4 = (nobs + 3) & ~3;
 #pragma unroll SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1
         for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, one ballot each
@@ -359,7 +398,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     // ---- adjoint, first term: the cross-track error through the arg-min segment of this stage ----
     double gx = 0.0, gy = 0.0;
     if (want_grad) {
-        const lds_double *sg = L + a.map.seg + SEG_STRIDE * bi;
+        const lds_double *sg = L + mp.seg + SEG_STRIDE * bi;
         const double px = xn - sg[0], py = yn - sg[1];
         const double dot = fma(px, sg[2], py * sg[3]);
         const double that = dot * sg[4];
@@ -379,7 +418,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             const bool two = rem != 0ull;
             const int k1 = two ? __builtin_ctzll(rem) : k0;
             rem &= rem - (two ? 1ull : 0ull);
-            const lds_double *o0 = L + a.map.obs + 3 * k0, *o1 = L + a.map.obs + 3 * k1;
+            const lds_double *o0 = L + mp.obs + 3 * k0, *o1 = L + mp.obs + 3 * k1;
             const double ax = o0[0], ay = o0[1], ar = o0[2], bx = o1[0], by = o1[1], br = o1[2];
             const double dx0 = xn - ax, dy0 = yn - ay, dx1 = xn - bx, dy1 = yn - by;
             const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar)), h1 = fma(-dy1, dy1, fma(-dx1, dx1, br));
@@ -506,20 +545,21 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     extern __shared__ double lds[];
     const int lane = threadIdx.x, g = lane / P, t = lane % P;
     const int gbase = g * P;
-    lds_double *L = (lds_double *)lds + g * a.map.total;
+    const LdsMap mp = the_map<SH, P>(a);
+    lds_double *L = (lds_double *)lds + g * mp.total;
     const int N = a.pb.N, m = a.op.lbfgs_memory;
     const bool in = t < N;
-    lds_double2 *LS = (lds_double2 *)(L + a.map.S);
-    lds_double2 *LY = (lds_double2 *)(L + a.map.Y);
-    lds_double *Lrho = L + a.map.rho;
+    lds_double2 *LS = (lds_double2 *)(L + mp.S);
+    lds_double2 *LY = (lds_double2 *)(L + mp.Y);
+    lds_double *Lrho = L + mp.rho;
 
     // ---- per-group state (every lane of a group holds the same control values) ----
     int state = ST_IDLE, inst = -1;
     bool done = false;                       // queue exhausted for this group
     double vref = 0.0;
     DynStage dyn;
-    dyn.col = L + a.map.dyn + t;
-    dyn.stride = P == 64 ? a.map.dyn_stride : P;
+    dyn.col = L + mp.dyn + t;
+    dyn.stride = P == 64 ? mp.dyn_stride : P;
     // horizon vectors: (v, w) pair per lane
     double uv = 0, uw = 0, gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0;   // u, grad, grad-step, half-step, gamma*fpr
     double dv = 0, dw = 0, pv = 0, pw = 0, qv = 0, qw = 0;                                      // direction, u_plus, previous gradient
@@ -575,7 +615,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
         // ------------------------------------------------------------------ one evaluation of psi per group
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         const bool wg = __any(live && need_grad);
-        eval_psi<P, SH>(a, L, a.map.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
+        eval_psi<P, SH>(a, L, mp.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
         if (!live) continue;
 
         // ------------------------------------------------------------------ consume it
@@ -1009,32 +1049,7 @@ static int fail(nmpc_handle *h, int code, const char *what, hipError_t e = hipSu
         if (e_ != hipSuccess) return fail((h), NMPC_ERR_HIP, #call, e_);       \
     } while (0)
 
-static LdsMap make_map(const nmpc_problem &pb, int m, int P)
-{
-    LdsMap mp;
-    int o = 0;
-    mp.sc = o;  o += 20;
-    mp.cw = o;  o += nmpc::CW_NCOEF;
-    mp.par = o; o += 16;
-    mp.seg = o; o += nmpc::SEG_STRIDE * (pb.N + 5);
-    mp.obs = o; o += 3 * (pb.nobs + 4);
-    const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
-    mp.f2 = o;  o += points * (pb.nobs + pb.ndyn + 1);
-    mp.rho = o; o += m;
-    const int cols = P == 20 ? 32 : P;                // >= nmpc::lay_cols; the hybrid kernel parks 32 state-layout columns
-    // one point per wave keeps its solver vectors in registers and needs ellipse columns for the real stages only: without
-    // the 64-column tables a 40-stage slice is 21.9 KB instead of 32.9 KB -- 7 resident waves per CU instead of 4
-    mp.dyn_stride = P == 64 ? ((pb.N + 1) & ~1) : (P == 20 ? nmpc::lay_cols<20>() : P);
-    mp.dyn = o; o += nmpc::NDYN_MAX * nmpc::DY_FIELDS * (P == 64 ? mp.dyn_stride : cols);
-    o = (o + 1) & ~1;
-    mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
-    o = (o + 1) & ~1;                       // 16-byte alignment for the double2 arrays
-    const int ring = P == 20 ? pb.N + 1 : pb.N;      // (+1: the hybrid kernel keeps an all-zero column per slot)
-    mp.S = o;   o += 2 * ring * m;
-    mp.Y = o;   o += 2 * ring * m;
-    mp.total = (o + 1) & ~1;
-    return mp;
-}
+static LdsMap make_map(const nmpc_problem &pb, int P) { return nmpc::lds_layout(pb.N, pb.nobs, pb.ndyn, P); }
 
 int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int max_batch, nmpc_handle **out)
 {
@@ -1065,7 +1080,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (const char *env = getenv("NMPC_SHAPE")) {              // experiments: force the run-time-shape kernel
         if (!strcmp(env, "any")) h->shape_default = h->shape_nobs50 = h->shape_n40 = false;
     }
-    h->map = make_map(*pb, op.lbfgs_memory, h->P);
+    h->map = make_map(*pb, h->P);
     h->d_queue = nullptr;
     h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
     h->park_min = 500; h->park_depth = 8;

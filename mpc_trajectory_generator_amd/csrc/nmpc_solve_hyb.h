@@ -91,28 +91,30 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
     // hold don't-care values: no cross-lane operation lets them into other lanes)
     constexpr bool FULL = SH::N == PE;
     const bool inea = FULL ? true : ine;
-    const int f2off = a.map.f2 + q * (a.n2 + 1);
+    const LdsMap mp = the_map<SH, PE>(a);
+    const int n2 = shape_nobs<SH>(a) + shape_ndyn<SH>(a);
+    const int f2off = mp.f2 + q * (n2 + 1);
     // evaluation-layout lane that holds stage t of query point 0 / 1 / 2 (state lanes beyond the horizon: themselves)
     const int src0 = in ? lay_lane<PE>(0, t) : lane, src1 = in ? lay_lane<PE>(1, t) : lane, src2 = in ? lay_lane<PE>(2, t) : lane;
     // state-layout lane that holds this evaluation lane's query point: X of half q (points 0, 1), Y (point 2)
     const int zsrcX = ine ? (q < 2 ? 32 * q + te : te) : lane, zsrcY = ine ? te : lane;
     // L-BFGS ring: N + 1 columns per slot, the last one all zeros -- lanes beyond the horizon read it
     const int NS = N + 1, tt = in ? t : N;
-    lds_double2 *LS = (lds_double2 *)(L + a.map.S);
-    lds_double2 *LY = (lds_double2 *)(L + a.map.Y);
-    lds_double *Lrho = L + a.map.rho;
-    lds_double2 *Los = (lds_double2 *)(L + a.map.vec) + t;      // parked pairs, one column per stage
+    lds_double2 *LS = (lds_double2 *)(L + mp.S);
+    lds_double2 *LY = (lds_double2 *)(L + mp.Y);
+    lds_double *Lrho = L + mp.rho;
+    lds_double2 *Los = (lds_double2 *)(L + mp.vec) + t;      // parked pairs, one column per stage
     lds_double2 *Log = Los + COLS, *Lq = Los + 2 * COLS, *Lyp = Los + 3 * COLS;
     lds_double2 *Lgk = Los + 6 * COLS;                          // gradient at the current iterate (opts.ls_failure = 1 only)
-    lds_double2 *LypE = (lds_double2 *)(L + a.map.vec) + 3 * COLS + te;      // the same columns, by evaluation lane
-    lds_double2 *Ly = (lds_double2 *)(L + a.map.vec) + 4 * COLS + te;        // multipliers y (read by every evaluation)
-    lds_double *Lvr = L + a.map.vec + 2 * 5 * COLS + te;                     // reference speed of this stage
+    lds_double2 *LypE = (lds_double2 *)(L + mp.vec) + 3 * COLS + te;      // the same columns, by evaluation lane
+    lds_double2 *Ly = (lds_double2 *)(L + mp.vec) + 4 * COLS + te;        // multipliers y (read by every evaluation)
+    lds_double *Lvr = L + mp.vec + 2 * 5 * COLS + te;                     // reference speed of this stage
     if (lane < m) { LS[lane * NS + N] = dbl2{0.0, 0.0}; LY[lane * NS + N] = dbl2{0.0, 0.0}; }
     NMPC_WAVE_SYNC();
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
     const unsigned budget = (unsigned)a.op.max_total_inner;     // 0 = off
-    lds_double *Lpar = L + a.map.par;
+    lds_double *Lpar = L + mp.par;
 #define pk_eps_nu Lpar[0]
 #define pk_dy_norm Lpar[1]
 #define pk_f2_norm Lpar[2]
