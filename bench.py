@@ -268,15 +268,29 @@ def main():
         seeds = {"ms_per_step": per_seed, "mean_ms": float(ms.mean()), "min_ms": float(ms.min()), "max_ms": float(ms.max()),
                  "mean_solves_per_s": float(B / (ms.mean() * 1e-3)),
                  "note": "seed 0 is the timed workload (`value`); seeds 1, 2: one untimed + two timed steps each"}
-        # (b) warm start: the batch re-solved from the previous solution and multipliers (c0 = 1)
+        # (b) warm start: the batch re-solved from ITS cold-start solution and multipliers (c0 = 1), every repetition from
+        # the same starting point (the kernel alone is timed, with events, so that restoring the start is not in the figure)
         step(warm=False)
-        step(warm=True)
-        wms = 1e3 * timed(2, warm=True)
+        fence()
+        u_cold, y_cold = d_u.clone(), d_y.clone()
+        wev = []
+        for _ in range(3):
+            d_u.copy_(u_cold)
+            d_y0.copy_(y_cold)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            solver.solve_device(d_p, d_u, d_y0, None, d_y, d_st)
+            e1.record()
+            wev.append((e0, e1))
+        fence()
+        wms = float(np.mean([a.elapsed_time(b) for a, b in wev[1:]]))
         stw = status_from_bytes(d_st)
         warm = {"value": B / (wms * 1e-3), "unit": "solves/s", "ms_per_step": wms,
                 "mean_inner_iters": float(stw["num_inner_iterations"].mean()),
                 "converged_frac": float((stw["exit_status"] == 0).mean()),
-                "roofline_frac": flops_of(stw) / (wms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS}
+                "roofline_frac": flops_of(stw) / (wms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
+                "note": "each repetition restarts from the cold-start solution and multipliers of the same batch"}
+        del u_cold, y_cold
         step(warm=False)                                                   # leave the cold-start results in the buffers
         fence()
     # (c) the same K steps with TWO batches in flight (two handles, two streams, own result buffers): the tail
