@@ -44,6 +44,41 @@ PEAK_F64_VALU_TFLOPS = 78.6      # MI355X vector f64 (= f64 MFMA dense peak); MI
 PEAK_HBM_GBS = 8000.0
 
 
+def usable_cores():
+    """Host threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a GPU lease
+    is typically a slice of the node: os.cpu_count() reports the node, not the lease)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+WORKLOADS = {   # what each BASELINE.json configuration is made of (mpc_trajectory_generator_amd/config.py named_config)
+    "cfg1": "configs/default.yaml",
+    "cfg2": "configs/default.yaml + jconf_3.yaml's lin_acc_penalty=100 with N_hor overridden to 40",
+    "cfg3": "configs/default.yaml with Nobs overridden to 50, all slots filled from a synthetic random-polygon circle field",
+    "cfg4": "configs/smooth_velocity.yaml's weights/bounds overlaid on default.yaml (N_hor=20), three random moving ellipses per instance",
+}
+POINTS_PER_PASS = {"nmpc_solve_hyb_kernel": 3, "nmpc_solve_n40_kernel": 3, "nmpc_solve_dual_kernel": 2, "nmpc_solve_kernel": 1}
+
+
 def flop_model(cfg):
     """Algorithmic flops (fma = 2, everything else incl. sin/cos/div = 1), DESIGN.md section 6."""
     N, Nobs, Ndyn = cfg.N_hor, cfg.Nobs, cfg.Ndynobs
@@ -236,6 +271,32 @@ def main():
         assert gather_ok, "gathered payload does not hold this rank's results"
         assert all((stg["num_inner_iterations"][r * B:(r + 1) * B] > 0).any() for r in range(world)), "a rank's slot is empty"
 
+    # per-rank report (device, shard, kernel ms) gathered to rank 0, and the gather alone (pack + all_gather), timed
+    # by events outside the timed region: a wrong rank -> device mapping or a slow link shows up in the line
+    ranks_report = gather_alone = None
+    if use_dist:
+        gev = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            shard.pack_results(d_payload, d_u, d_y, d_st)
+            shard.gather_shards(d_payload, out=d_gather)
+            e1.record()
+            gev.append((e0, e1))
+        fence()
+        gms = float(np.mean([a.elapsed_time(b) for a, b in gev[1:]]))
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "local_rank": local, "device": torch.cuda.current_device(), "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "shard": [rank * B, (rank + 1) * B],
+                "kernel_ms": kern_ms, "gather_ms": gms, "host": socket.gethostname()}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        ranks_report = allr
+        gather_alone = {"ms": max(r["gather_ms"] for r in allr), "bytes_per_rank": int(d_payload.numel() * 8),
+                        "what": "pack_results + one all_gather_into_tensor, HIP events, max over ranks"}
+        devs = [r["device"] for r in allr if r["host"] == mine["host"]]
+        assert len(set(devs)) == len(devs), f"two ranks share a device: {allr}"
+
     f_fwd, f_bwd, f_iter = flop_model(cfg)
 
     def flops_of(s):
@@ -293,6 +354,34 @@ def main():
         del u_cold, y_cold
         step(warm=False)                                                   # leave the cold-start results in the buffers
         fence()
+    # (b2) the other values of the one restatement switch that moves the headline by a large factor,
+    # timed by HIP events on the same batch, one warm-up + one timed step each
+    variants = None
+    if extras_ok:
+        variants = {}
+        for val in (0, 1, 2):
+            if val == solver.opts.akkt_gradient:
+                continue
+            sv = BatchSolver(cfg, max_batch=B, device=local, akkt_gradient=val)
+            vev = []
+            for _ in range(2):
+                d_u.zero_()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sv.solve_device(d_p, d_u, None, None, d_y, d_st)
+                e1.record()
+                vev.append((e0, e1))
+            fence()
+            vms = float(vev[1][0].elapsed_time(vev[1][1]))
+            stv = status_from_bytes(d_st)
+            variants[f"akkt_gradient={val} ({sv.variant['akkt_gradient']})"] = {
+                "value": B / (vms * 1e-3), "unit": "solves/s", "ms_per_step": vms,
+                "mean_inner_iters": float(stv["num_inner_iterations"].mean()),
+                "converged_frac": float((stv["exit_status"] == 0).mean()),
+                "roofline_frac": flops_of(stv) / (vms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS}
+            sv.close()
+        step(warm=False)                                                   # leave the default variant's results in the buffers
+        fence()
     # (c) the same K steps with TWO batches in flight (two handles, two streams, own result buffers): the tail
     # of one batch overlaps the bulk of the next, which is how a service that receives batch after batch would
     # run the solver.  Reported under "pipelined", never as `value`.
@@ -325,7 +414,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: default.yaml-shaped NMPC, N_hor={cfg.N_hor}, Nobs={cfg.Nobs}, "
+        "config": {"workload": f"{args.config}: {WORKLOADS.get(args.config, args.config)}; N_hor={cfg.N_hor}, Nobs={cfg.Nobs}, "
                                f"Ndynobs={cfg.Ndynobs}, scene {args.scene} ({args.routes or 1} route(s): "
                                f"{'randomised start/goal planned by the visibility-graph front-end' if args.routes else 'scene start->end'}), "
                                f"batch={B}/GPU, {'WARM start (previous solution and multipliers, c0=1)' if args.warm else 'cold start (u0=0, y0=0, c0=1)'}, "
@@ -340,14 +429,17 @@ def main():
         # reference would apply, src/path_generator.py:393-394); the converged ones alone:
         "converged": {"value": value * stats[2] / stats[3], "unit": "converged solves/s",
                       "mean_inner_iters": stats[4] / max(stats[2], 1.0)},
-        "gather_checked": gather_ok,
-        "seeds": seeds, "warm_start": warm, "pipelined": pipelined,
+        "gather_checked": gather_ok, "gather_alone": gather_alone, "ranks": ranks_report,
+        "seeds": seeds, "warm_start": warm, "pipelined": pipelined, "variants": variants,
         "p50_inner_iters": float(np.median(st["num_inner_iterations"])),
         "p99_inner_iters": float(np.percentile(st["num_inner_iterations"], 99)),
         "max_inner_iters": int(st["num_inner_iterations"].max()),
         # the batch ends with its slowest instance: its evaluation passes, and the batch time spread over them
         "critical_instance": {"passes": int(st["reserved"].max()), "kernel_us_per_critical_pass": 1e3 * kern_ms / max(int(st["reserved"].max()), 1),
-                              "mean_passes": float(st["reserved"].mean())},
+                              "mean_passes": float(st["reserved"].mean()),
+                              "points_per_pass": POINTS_PER_PASS.get(solver.kernel_name.split("<")[0]),
+                              "slowest_instance_ms": float(st["solve_time_ms"].max()),
+                              "mean_instance_ms": float(st["solve_time_ms"].mean())},
         # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s);
         # the kernel issues no MFMA -- "bound_detail" says what actually limits it
         "roofline": {"bound": "mfma", "bound_detail": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
@@ -367,7 +459,7 @@ def main():
         from oracle import Oracle
         orc = Oracle(cfg.N_hor, cfg.Nobs, cfg.Ndynobs, cfg.ts, cfg.lin_vel_min, cfg.lin_vel_max, cfg.ang_vel_max,
                      cfg.lin_acc_min, cfg.lin_acc_max, cfg.ang_acc_max, **solver.oracle_opts())
-        cores = os.cpu_count() or 1
+        cores, quota = usable_cores()                            # threads = the cores this process may run on
         n0 = min(B, 4 * cores)
         t = time.perf_counter()
         orc.solve_batch(P_host[:n0], threads=cores)
@@ -386,7 +478,9 @@ def main():
         t = time.perf_counter()
         orc.solve_batch(P_host[:n1t], threads=1)
         dt1 = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": cores, "threads": cores, "kind": "port",
+                               "host_cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota,
+                               "speedup_over_one_thread": (n / dt) / (n1t / dt1),
                                "sample": f"first {n} instances of the rank-0 batch, {cores} host threads pulling from a "
                                          f"shared work queue, {dt:.1f} s; oracle/nmpc_oracle.c -O3 (restatement; OpEn not buildable)",
                                "single_thread": {"value": n1t / dt1, "unit": "solves/s", "sample": f"first {n1t} instances, {dt1:.1f} s"},

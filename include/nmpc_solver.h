@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define NMPC_ABI_VERSION 2
+#define NMPC_ABI_VERSION 3
 
 typedef enum nmpc_error {
     NMPC_OK = 0,
@@ -96,7 +96,11 @@ typedef enum nmpc_exit {
     NMPC_NOT_CONVERGED_ITERATIONS = 1,
     NMPC_NOT_CONVERGED_OUT_OF_TIME = 2,      /* opts.max_total_inner spent (deterministic max_duration) */
     NMPC_NOT_CONVERGED_COST = 3,
-    NMPC_NOT_CONVERGED_NOT_FINITE = 4
+    NMPC_NOT_CONVERGED_NOT_FINITE = 4        /* Deviation from OpEn, which checks the returned u only: raised as well when
+                                                the cost or the residual norm ||r|| of an inner solve is not finite
+                                                while the projected half step u still is (e.g. an initial penalty that
+                                                overflows psi).  Through tcp_shim this is error 2000; the reference
+                                                would go on with clamped controls (tests: test_nonfinite_cost_*) */
 } nmpc_exit;
 
 /* One per instance: the fields of OpEn's solver status plus evaluation
@@ -107,13 +111,19 @@ typedef struct nmpc_status {
     uint32_t num_inner_iterations;
     uint32_t num_cost_evals;         /* forward-only evaluations of psi             */
     uint32_t num_grad_evals;         /* forward + adjoint evaluations               */
-    uint32_t reserved;               /* diagnostic: evaluation passes the kernel executed         */
+    uint32_t reserved;               /* diagnostic: evaluation passes this solve needs in the kernel's schedule --
+                                        three query points per pass (nmpc_solve_hyb_kernel, N_hor <= 20; a pass whose
+                                        trials were evaluated by helper waves of the team counts like one the owner
+                                        ran itself, so the figure is deterministic), two (nmpc_solve_dual_kernel),
+                                        one (nmpc_solve_kernel<64>: = num_cost_evals + num_grad_evals)      */
     double last_problem_norm_fpr;
     double delta_y_norm_over_c;
     double f2_norm;
     double penalty;
     double cost;
-    double solve_time_ms;            /* batch wall time / 1 (host path); 0 on the device path */
+    double solve_time_ms;            /* THIS instance: first start -> finish on the device's constant 100 MHz clock
+                                        (what the reference reads per solve, src/mpc/mpc_generator.py:214); the
+                                        wall time of a whole host-path batch is nmpc_last_batch_ms()          */
 } nmpc_status;
 
 typedef struct nmpc_handle nmpc_handle;
@@ -149,6 +159,8 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 /* Host path: same operands in host memory; copies in, solves, copies out, synchronises. */
 int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, const double *y0,
                           const double *c0, double *y_out, nmpc_status *status);
+/* Kernel time (HIP events around the launch) of the last nmpc_solve_batch_host call on this handle, in ms. */
+double nmpc_last_batch_ms(const nmpc_handle *h);
 
 /* psi(u; c, y, p), grad_u psi, F1, F2 for B instances (c == NULL: zeros -> plain f; y == NULL: zeros).
  * Outputs may be NULL.  psi [B], grad [B][n_u], F1 [B][n1], F2 [B][n2]. */

@@ -18,11 +18,13 @@ LIB_PATH = os.path.join(_CSRC, "libnmpc_hip.so")
 SYMBOLS = (
     "nmpc_default_opts", "nmpc_n_u", "nmpc_n_p", "nmpc_n1", "nmpc_n2", "nmpc_new", "nmpc_free",
     "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_kernel_name", "nmpc_solve_batch_device",
-    "nmpc_solve_batch_host", "nmpc_eval_batch_device", "nmpc_eval_batch_host",
+    "nmpc_solve_batch_host", "nmpc_last_batch_ms", "nmpc_eval_batch_device", "nmpc_eval_batch_host",
     "nmpc_test_sincos_host", "nmpc_test_divsqrt_host",
     "nmpc_loop_new", "nmpc_loop_free", "nmpc_loop_step", "nmpc_loop_read", "nmpc_loop_params",
     "nmpc_loop_trajectory",
 )
+
+EXPECTED_ABI = 3      # the nmpc_opts / nmpc_status layouts below are written for this version of include/nmpc_solver.h
 
 ERRORS = {0: "ok", -1: "bad problem", -2: "bad opts", -3: "bad argument", -4: "no HIP device",
           -5: "HIP runtime error", -6: "dead handle"}
@@ -126,6 +128,10 @@ def load_library() -> C.CDLL:
         return _lib
     path = os.environ.get("NMPC_LIB_PATH") or build_library()      # (NMPC_LIB_PATH: instrumented builds, scripts/ only)
     lib = C.CDLL(path)
+    lib.nmpc_abi_version.restype = C.c_int
+    if lib.nmpc_abi_version() != EXPECTED_ABI:      # a stale / foreign .so would silently misread nmpc_opts
+        raise RuntimeError(f"{path}: ABI version {lib.nmpc_abi_version()}, this package expects {EXPECTED_ABI} "
+                           "(rebuild: make -C mpc_trajectory_generator_amd/csrc -B)")
     dp, vp = C.POINTER(C.c_double), C.c_void_p
     lib.nmpc_default_opts.argtypes = [C.POINTER(NmpcOpts)]
     lib.nmpc_default_opts.restype = None
@@ -140,7 +146,8 @@ def load_library() -> C.CDLL:
     lib.nmpc_last_error.restype = C.c_char_p
     lib.nmpc_kernel_name.argtypes = [vp]
     lib.nmpc_kernel_name.restype = C.c_char_p
-    lib.nmpc_abi_version.restype = C.c_int
+    lib.nmpc_last_batch_ms.argtypes = [vp]
+    lib.nmpc_last_batch_ms.restype = C.c_double
     lib.nmpc_solve_batch_device.argtypes = [vp, C.c_int] + [vp] * 7
     lib.nmpc_solve_batch_host.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, vp]
     lib.nmpc_eval_batch_device.argtypes = [vp, C.c_int] + [vp] * 9

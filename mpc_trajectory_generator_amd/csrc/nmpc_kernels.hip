@@ -577,7 +577,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     // ALM scalars
     double pen_c = 1, eps_nu = 0, dy_norm = 0, f2_norm = 0, dy_norm_plus = 0, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
     int nu = 0, inner_status = 0;
-    unsigned inner_total = 0, n_cost = 0, n_grad = 0;
+    unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
+    long long t_start = 0;                   // 100 MHz clock at the fetch: per-instance solve_time_ms
 
     for (;;) {
         // ------------------------------------------------------------------ fetch work
@@ -589,6 +590,8 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 done = true;
             } else {
                 inst = a.order ? a.order[nxt] : (int)nxt;
+                t_start = (long long)__builtin_amdgcn_s_memrealtime();
+                n_pass = 0;
                 prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
                 const double *u0 = a.u + (size_t)inst * a.n_u;
                 uv = in ? u0[2 * t] : 0.0;
@@ -617,6 +620,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
         const bool wg = __any(live && need_grad);
         eval_psi<P, SH>(a, L, mp.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
         if (!live) continue;
+        n_pass++;
 
         // ------------------------------------------------------------------ consume it
         bool begin_step = false;      // (u, cost, g, grad-step, half-step) consistent: start the next PANOC step
@@ -859,13 +863,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 s.num_inner_iterations = inner_total;
                 s.num_cost_evals = n_cost;
                 s.num_grad_evals = n_grad;
-                s.reserved = 0;
+                s.reserved = n_pass;                 // evaluation passes executed (one query point each)
                 s.last_problem_norm_fpr = last_fpr;
                 s.delta_y_norm_over_c = dy_norm_plus / pen_c;
                 s.f2_norm = f2_norm_plus;
                 s.penalty = pen_c;
                 s.cost = last_cost;
-                s.solve_time_ms = 0.0;
+                s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - t_start) * 1e-5;
                 a.st[inst] = s;
             }
             state = ST_IDLE;
@@ -994,6 +998,7 @@ struct nmpc_handle {
     bool shape_nobs50;     // ... == ShapeNobs50
     bool shape_n40;        // ... == ShapeN40
     int grid_cap;          // resident waves the launch is sized for
+    double last_ms;        // kernel time of the last host-path batch
     unsigned int *d_queue;
     int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
     double *d_park;            // parked solver states, allocated on first use
@@ -1022,7 +1027,7 @@ void nmpc_default_opts(nmpc_opts *o)
     o->max_inner = 500;
     o->max_outer = 10;
     o->max_total_inner = 0;
-    o->akkt_gradient = 0;
+    o->akkt_gradient = 1;      // step_top: OpEn caches the previous gradient at the top of step()
     o->ls_failure = 0;
     o->inner_status = 0;
     o->reserved = 0;
@@ -1067,7 +1072,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
         return NMPC_ERR_NO_DEVICE;
     nmpc_handle *h = new nmpc_handle();
-    h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true;
+    h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true; h->last_ms = 0.0;
     h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : 64);
     if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments / cross-checks: force the two-point layout
         if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
@@ -1126,6 +1131,7 @@ void nmpc_free(nmpc_handle *h)
 
 int nmpc_ping(const nmpc_handle *h) { return (h && h->alive) ? NMPC_OK : NMPC_ERR_DEAD_HANDLE; }
 const char *nmpc_last_error(const nmpc_handle *h) { return h ? h->err.c_str() : "null handle"; }
+double nmpc_last_batch_ms(const nmpc_handle *h) { return h ? h->last_ms : 0.0; }
 const char *nmpc_kernel_name(const nmpc_handle *h)
 {
     if (!h) return "";
@@ -1268,11 +1274,11 @@ int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, con
     if (e1) (void)hipEventDestroy(e1);
     if (rc) return rc;
     if (he != hipSuccess) return fail(h, NMPC_ERR_HIP, "solve_batch_host", he);
+    h->last_ms = (double)ms;
     HIP_TRY(h, hipMemcpy(u, h->d_u, B * nu * 8, hipMemcpyDeviceToHost));
     if (y_out) HIP_TRY(h, hipMemcpy(y_out, h->d_yout, B * n1 * 8, hipMemcpyDeviceToHost));
     if (status) {
         HIP_TRY(h, hipMemcpy(status, h->d_st, B * sizeof(nmpc_status), hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; ++b) status[b].solve_time_ms = (double)ms;     // wall time of the whole batch
     }
     return NMPC_OK;
 }

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
         if (nxt >= (unsigned)a.B) break;
         const int inst = a.order ? a.order[nxt] : (int)nxt;
+        const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz: per-instance solve_time_ms
 
         double vref;
         DynStage dyn;
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
             s.f2_norm = f2_norm_plus;
             s.penalty = pen_c;
             s.cost = last_cost;
-            s.solve_time_ms = 0.0;
+            s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - t_start) * 1e-5;
 #ifdef NMPC_PROFILE
             {
                 extern __shared__ long long nmpc_prof_lds[];

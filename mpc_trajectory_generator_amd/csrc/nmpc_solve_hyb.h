@@ -136,13 +136,14 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
     const int PS = park_stride(N);
 
     // first round: the queue's head -- the instances that look hardest -- goes to the favoured wave slots; the other
-    // waves hold back until half of the resident waves have fetched (bounded: they go ahead after ~40 us regardless)
-    if (a.order && unfavoured && a.park_min > 0) {
-        const unsigned want = (unsigned)(a.B < 2 * (int)gridDim.x ? a.B / 2 : (int)gridDim.x / 2);
-        for (int spin = 0; spin < 400; ++spin) {
-            if (__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+    // waves hold back until half of the resident waves have fetched.  Bounded by the constant 100 MHz clock (40 us),
+    // and skipped when the queue holds barely more than one round (nothing to gain from ordering the first fetches)
+    if (a.order && unfavoured && a.park_min > 0 && a.B >= (int)gridDim.x + (int)(gridDim.x >> 2)) {
+        const unsigned want = gridDim.x / 2;
+        const long long t_hold = (long long)__builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+               (long long)__builtin_amdgcn_s_memrealtime() - t_hold < 4000)
             __builtin_amdgcn_s_sleep(8);
-        }
     }
 
     for (;;) {
@@ -637,7 +638,9 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             s.f2_norm = pk_f2_norm_plus;
             s.penalty = pen_c;
             s.cost = pk_last_cost;
-            s.solve_time_ms = 0.0;
+            // first start -> finish on the constant 100 MHz clock (the parked time of a migrated instance included): what the
+            // reference reads per solve (src/mpc/mpc_generator.py:214)
+            s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - (long long)Lpar[13]) * 1e-5;
             if (a.dbg) {       // cycles spent on this instance, wave slot, finish time on the 100 MHz reference clock
                 s.last_problem_norm_fpr = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
                 s.f2_norm = (double)hw_slot;

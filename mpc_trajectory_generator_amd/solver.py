@@ -81,6 +81,12 @@ class BatchSolver:
         """Name of the solve kernel this handle launches (diagnostic; what a kernel trace shows)."""
         return self.lib.nmpc_kernel_name(self._h).decode()
 
+    @property
+    def last_batch_ms(self) -> float:
+        """Kernel time (HIP events) of the last host-path ``solve`` on this handle; per-instance times are in
+        ``status["solve_time_ms"]``."""
+        return float(self.lib.nmpc_last_batch_ms(self._h))
+
     def ping(self):
         self._check(self.lib.nmpc_ping(self._h))
 

@@ -201,7 +201,7 @@ void orc_default_opts(orc_opts *o)
     o->max_inner = 500;
     o->max_outer = 10;
     o->max_total_inner = 0;
-    o->akkt_gradient = 0;
+    o->akkt_gradient = 1;
     o->ls_failure = 0;
     o->inner_status = 0;
     o->reserved = 0;

@@ -13,4 +13,4 @@ for B in (1, 64, 256, 512, 1024, 2048, 4096, 8192):
     Pb = np.repeat(p, B, axis=0)
     sol.solve(Pb)
     _, _, s = sol.solve(Pb)
-    print(f"B={B:5d}: kernel {s['solve_time_ms'][0]:8.2f} ms  passes/inst {s['reserved'][0]}  -> {1e3*s['solve_time_ms'][0]/s['reserved'][0]/max(1,-(-B//2048)):.2f} us/pass/round")
+    print(f"B={B:5d}: kernel {sol.last_batch_ms:8.2f} ms  passes/inst {s['reserved'][0]}  -> {1e3*sol.last_batch_ms/s['reserved'][0]/max(1,-(-B//2048)):.2f} us/pass/round")

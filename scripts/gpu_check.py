@@ -48,7 +48,7 @@ for name in ["default", "n40", "nobs50", "smooth"]:
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 P = synthetic_batch(cfg, 11, B, 12345)
 t = time.time(); u, y, st = sol.solve(P); dt = time.time() - t
-print(f"GPU solve B={B}: {dt*1e3:.1f} ms wall, kernel {st['solve_time_ms'][0]:.2f} ms")
+print(f"GPU solve B={B}: {dt*1e3:.1f} ms wall, kernel {sol.last_batch_ms:.2f} ms")
 t = time.time(); uo, yo, sto = orc.solve_batch(P, threads=8); dto = time.time() - t
 print(f"oracle: {dto:.2f} s")
 same_u = np.array([np.array_equal(u[i], uo[i]) for i in range(B)])

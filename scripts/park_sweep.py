@@ -12,6 +12,6 @@ out = {"min": os.environ.get("NMPC_PARK_MIN"), "depth": os.environ.get("NMPC_PAR
 for seed in (0, 1, 2):
     P = synthetic_batch(cfg, 11, 8192, seed, routes=random_routes(cfg, 11, 32, seed=1000 + seed))
     sol.solve(P)
-    out[f"s{seed}"] = round(min(float(sol.solve(P)[2]["solve_time_ms"][0]) for _ in range(3)), 1)
+    out[f"s{seed}"] = round(min((sol.solve(P), sol.last_batch_ms)[1] for _ in range(3)), 1)
 out["mean"] = round((out["s0"] + out["s1"] + out["s2"]) / 3, 1)
 print(json.dumps(out))

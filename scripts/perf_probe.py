@@ -24,19 +24,21 @@ for seed in (0, 1, 2):
     if seed == 0:
         P0 = P
     sol.solve(P)
-    ms = [float(sol.solve(P)[2]["solve_time_ms"][0]) for _ in range(3)]
+    ms = [(sol.solve(P), sol.last_batch_ms)[1] for _ in range(3)]
     st = sol.solve(P)[2]
     out[f"seed{seed}_ms"] = round(min(ms), 2)
     out[f"seed{seed}_maxpass"] = int(st["reserved"].max())
     if seed == 0:
         out["checksum"] = float(st["num_inner_iterations"].astype(np.float64).sum() + st["cost"].sum())
-for b in (170, 4175):
+slowest = np.argsort(-sol.solve(P0)[2]["reserved"].astype(np.int64))[:2]
+for b in (int(slowest[0]), int(slowest[1])):
     sol.solve(P0[b:b + 1])
     s = sol.solve(P0[b:b + 1])[2]
-    out[f"lone{b}_us_per_pass"] = round(1e3 * float(s["solve_time_ms"][0]) / int(s["reserved"][0]), 3)
-    out[f"lone{b}_ms"] = round(float(s["solve_time_ms"][0]), 2)
-Pc = np.repeat(P0[170:171], 2048, axis=0)
+    out[f"lone{b}_passes"] = int(s["reserved"][0])
+    out[f"lone{b}_us_per_pass"] = round(1e3 * sol.last_batch_ms / int(s["reserved"][0]), 3)
+    out[f"lone{b}_ms"] = round(sol.last_batch_ms, 2)
+Pc = np.repeat(P0[int(slowest[0]):int(slowest[0]) + 1], 2048, axis=0)
 sol.solve(Pc)
 s = sol.solve(Pc)[2]
-out["crowd_us_per_pass"] = round(1e3 * float(s["solve_time_ms"][0]) / int(s["reserved"][0]), 3)
+out["crowd_us_per_pass"] = round(1e3 * sol.last_batch_ms / int(s["reserved"][0]), 3)
 print(json.dumps(out))

@@ -20,6 +20,6 @@ for B in (1, 1024, 2048):
     slot = s["f2_norm"].astype(int)                      # hardware wave slot within the SIMD (debug fields of the status)
     ev, od = c[slot % 2 == 0], c[slot % 2 == 1]
     print("  wave slots used:", np.bincount(slot))
-    print(f"dbg={os.environ.get('NMPC_DEBUG_PRIO')} B={B}: kernel {s['solve_time_ms'][0]:.1f} ms, {s['reserved'][0]} passes, "
-          f"{1e3 * s['solve_time_ms'][0] / s['reserved'][0]:.2f} us/pass; cycles/1e6 even: mean {ev.mean()/1e6:.1f} min {ev.min()/1e6:.1f} max {ev.max()/1e6:.1f}"
+    print(f"dbg={os.environ.get('NMPC_DEBUG_PRIO')} B={B}: kernel {sol.last_batch_ms:.1f} ms, {s['reserved'][0]} passes, "
+          f"{1e3 * sol.last_batch_ms / s['reserved'][0]:.2f} us/pass; cycles/1e6 even: mean {ev.mean()/1e6:.1f} min {ev.min()/1e6:.1f} max {ev.max()/1e6:.1f}"
           + (f" | odd: mean {od.mean()/1e6:.1f} min {od.min()/1e6:.1f} max {od.max()/1e6:.1f}" if len(od) else ""))

@@ -16,6 +16,6 @@ order = np.argsort(-ps)[:6]
 for b in order:
     _, _, s = sol.solve(P[b:b + 1])
     print(f"inst {b}: passes {ps[b]} iters {st['num_inner_iterations'][b]} outer {st['num_outer_iterations'][b]} grad evals {st['num_grad_evals'][b]} cost evals {st['num_cost_evals'][b]} "
-          f"penalty {st['penalty'][b]:.3g} exit {st['exit_status'][b]} lone {s['solve_time_ms'][0]:.1f} ms")
+          f"penalty {st['penalty'][b]:.3g} exit {st['exit_status'][b]} lone {sol.last_batch_ms:.1f} ms")
 hist = np.histogram(ps, bins=[0, 500, 1000, 2000, 4000, 6000, 8000, 10000, 12000, 16000, 20000])
 print(hist)

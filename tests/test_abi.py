@@ -19,7 +19,7 @@ def test_header_symbols_exported():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nmpc_abi_version() == 2
+    assert lib.nmpc_abi_version() == _lib.EXPECTED_ABI == 3
 
 
 def test_sizes_and_struct_layout():
@@ -35,8 +35,8 @@ def test_sizes_and_struct_layout():
     o = _lib.NmpcOpts()
     lib.nmpc_default_opts(ctypes.byref(o))
     assert (o.tolerance, o.lbfgs_memory, o.max_inner, o.max_outer, o.initial_penalty) == (1e-4, 10, 500, 10, 1.0)
-    # the budget is off and every restatement switch is at its round-1 value by default
-    assert (o.max_total_inner, o.akkt_gradient, o.ls_failure, o.inner_status) == (0, 0, 0, 0)
+    # the budget is off; akkt_gradient defaults to 1 (step_top), the other switches to 0
+    assert (o.max_total_inner, o.akkt_gradient, o.ls_failure, o.inner_status) == (0, 1, 0, 0)
 
 
 def test_oracle_and_abi_share_option_fields():

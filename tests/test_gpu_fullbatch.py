@@ -63,8 +63,10 @@ def test_full_batch_properties_and_sampled_parity(name, kernel, sample):
         s.close()
 
 
-def test_cfg4_device_loop_full_fleet():
-    """BASELINE config 4 at fleet size: 8192 robots x 10 receding-horizon steps entirely on device (assembly,
+@pytest.mark.parametrize("steps,n_mirror", [(10, 24), (100, 8)], ids=["10steps-24robots", "100steps-8robots"])
+def test_cfg4_device_loop_full_fleet(steps, n_mirror):
+    """BASELINE config 4 at fleet size: 8192 robots x 10 receding-horizon steps -- and the configuration's stated 100
+    steps (configs/smooth_velocity.yaml:17 num_steps_taken = 2; src/path_generator.py:290-403) -- entirely on device (assembly,
     warm-started solve, state advance), checked against the host mirror on a sample of robots -- a robot's
     parameter vectors, states and controls depend on nobody else in the fleet, so the mirror can run the sample
     alone and must reproduce it bit for bit."""
@@ -73,7 +75,7 @@ def test_cfg4_device_loop_full_fleet():
     cfg = named_config("cfg4")
     route = harness.scene_route(cfg, 11)
     rng = np.random.Generator(np.random.PCG64(0))
-    n, K, steps = len(route.x_ref), cfg.Ndynobs, 10
+    n, K = len(route.x_ref), cfg.Ndynobs
     xr, yr, tr = np.array(route.x_ref), np.array(route.y_ref), np.array(route.theta_ref)
     i0 = rng.integers(0, max(1, n - 60), B)
     starts = np.stack([xr[i0] + rng.normal(0, 0.05, B), yr[i0] + rng.normal(0, 0.05, B), tr[i0] + rng.normal(0, 0.1, B)], axis=1)
@@ -81,7 +83,7 @@ def test_cfg4_device_loop_full_fleet():
     c = np.stack([xr[jj], yr[jj]], axis=2)
     dyn = (c + rng.uniform(-5, 5, (B, K, 2)), c + rng.uniform(-5, 5, (B, K, 2)), rng.uniform(0.05, 0.1, (B, K)),
            rng.uniform(0.3, 1.0, (B, K)), rng.uniform(0.3, 1.0, (B, K)), rng.uniform(0, np.pi, (B, K)))
-    ids = np.sort(np.random.default_rng(2).choice(B, 24, replace=False))
+    ids = np.sort(np.random.default_rng(2).choice(B, n_mirror, replace=False))
     o = oracle_for(cfg)
     s = BatchSolver(cfg, max_batch=B)
     try:
@@ -91,7 +93,7 @@ def test_cfg4_device_loop_full_fleet():
         for k in range(steps):
             dev.step()
             P, st = host.step(lambda P_, U, Y: o.solve_batch(P_, u0=U, y0=Y, threads=8))
-            if k in (0, 1, steps - 1):
+            if k in (0, 1, steps // 2, steps - 1):
                 Pd, Ud, Yd = dev.params()
                 assert np.array_equal(Pd[ids], P), f"step {k}"
                 assert np.array_equal(Ud[ids], host.U) and np.array_equal(Yd[ids], host.Y)

@@ -161,9 +161,9 @@ def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
 
 # restatement switches (include/nmpc_solver.h): every value of every switch, alone and
 # combined, in every solve kernel -- hybrid (N <= 20), dual (20 < N <= 32), one-point (N > 32)
-SWITCHES = [dict(akkt_gradient=1), dict(akkt_gradient=2), dict(ls_failure=1), dict(inner_status=1),
-            dict(akkt_gradient=1, ls_failure=1, inner_status=1), dict(max_total_inner=150),
-            dict(max_total_inner=700, ls_failure=1, akkt_gradient=1)]
+SWITCHES = [dict(akkt_gradient=0), dict(akkt_gradient=2), dict(ls_failure=1), dict(inner_status=1),
+            dict(akkt_gradient=0, ls_failure=1, inner_status=1), dict(max_total_inner=150),
+            dict(max_total_inner=700, ls_failure=1, akkt_gradient=0)]
 
 
 @pytest.mark.parametrize("opts", SWITCHES, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
@@ -175,7 +175,7 @@ def test_restatement_switches_bit_exact(N, opts):
     P = synthetic_batch(cfg, 11, 48 if N == 20 else 16, 777 + N)
     s = BatchSolver(cfg, max_batch=64, **opts)
     try:
-        assert s.variant["akkt_gradient"] == ("per_trial", "step_top", "off")[opts.get("akkt_gradient", 0)]
+        assert s.variant["akkt_gradient"] == ("per_trial", "step_top", "off")[opts.get("akkt_gradient", 1)]
         gpu = s.solve(P)
         cpu = oracle_for(cfg, **s.oracle_opts()).solve_batch(P, threads=8)
         assert_same_solution(gpu, cpu)
@@ -406,3 +406,46 @@ def test_fuzz_shapes_and_options():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "32", "7"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "mismatches: 0 of 32" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_nonfinite_cost_with_finite_controls_matches_the_oracle(solvers):
+    """A penalty that overflows psi: the projected half step u stays finite (it is clamped to U) while the cost and
+    the residual are not.  Kernels and oracle both end such a solve with NotConvergedNotFiniteComputation (OpEn itself
+    checks u only -- the deviation is listed in include/nmpc_solver.h); the instances are isolated here so that the
+    branch is covered by a bit-exact parity case of its own."""
+    cfg = named_config("cfg1")
+    P = synthetic_batch(cfg, 11, 16, 4242)
+    for c0 in (1e306, 1e308):
+        gpu = solvers("cfg1").solve(P, c0=np.full(16, c0))
+        cpu = oracle_for(cfg).solve_batch(P, c0=np.full(16, c0), threads=8)
+        assert (gpu[2]["exit_status"] == 4).any() and np.all(np.isfinite(gpu[0]))
+        assert np.array_equal(gpu[2]["exit_status"], cpu[2]["exit_status"])
+        assert np.array_equal(gpu[0], cpu[0]) and np.array_equal(gpu[2]["num_inner_iterations"], cpu[2]["num_inner_iterations"])
+        bad = gpu[2]["exit_status"] == 4
+        assert not np.all(np.isfinite(gpu[2]["cost"][bad]) & np.isfinite(gpu[2]["last_problem_norm_fpr"][bad]))
+
+
+@pytest.mark.parametrize("name,B", [("cfg1", 4096), ("cfg1", 1), ("cfg2", 512), ("cfg1-dual", 512)])
+def test_per_instance_solve_time(solvers, name, B, monkeypatch):
+    """status.solve_time_ms is THIS instance's first-start -> finish time on the device clock (the reference reads
+    it per solve, src/mpc/mpc_generator.py:214, and derives its loop overhead from it, src/path_generator.py:387,402-403):
+    positive, never above the kernel time of the batch, and growing with the work the instance needed."""
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    if name.endswith("-dual"):
+        monkeypatch.setenv("NMPC_LAYOUT", "dual")
+    cfg = named_config(name.split("-")[0])
+    P = synthetic_batch(cfg, 11, B, 31337)
+    s = BatchSolver(cfg, max_batch=B)
+    try:
+        s.solve(P)
+        _, _, st = s.solve(P)
+        batch_ms = s.last_batch_ms
+    finally:
+        s.close()
+    t = st["solve_time_ms"]
+    assert np.all(t > 0.0) and np.all(t <= batch_ms * 1.02 + 0.05), (t.min(), t.max(), batch_ms)
+    assert t.max() >= 0.5 * batch_ms - 0.05                   # somebody ran (nearly) to the end of the launch
+    if B > 1:
+        work = st["reserved"].astype(np.float64)
+        assert np.corrcoef(work, t)[0, 1] > 0.8
+        assert t[np.argmax(work)] > np.median(t)

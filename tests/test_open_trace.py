@@ -74,7 +74,7 @@ def test_replay_logic_on_a_synthetic_trace():
     (and only variants indistinguishable from it on this trace) with zero error, and the others worse -- so a real
     OpEn trace would identify the right switches."""
     cfg = named_config("cfg1")
-    truth = dict(akkt_gradient=1, ls_failure=1, inner_status=0, keep_multipliers=False)
+    truth = dict(akkt_gradient=0, ls_failure=1, inner_status=0, keep_multipliers=False)
     P = synthetic_batch(cfg, 11, 3, 5)
     sw = dict(truth)
     sw.pop("keep_multipliers")
@@ -91,7 +91,7 @@ def test_replay_logic_on_a_synthetic_trace():
     rows = rank_variants(trace, cfg)
     perfect = [sw_ for sc, sw_ in rows if sc == (1.0, 0.0, 0.0)]
     assert truth in perfect and rows[0][0] == (1.0, 0.0, 0.0)
-    assert all(sw_["akkt_gradient"] == 1 and sw_["ls_failure"] == 1 for sw_ in perfect)     # the trace tells them apart
+    assert all(sw_["akkt_gradient"] == 0 and sw_["ls_failure"] == 1 for sw_ in perfect)     # the trace tells them apart
     assert len(perfect) < len(rows)
 
 
@@ -106,7 +106,7 @@ def test_shipped_variant_reproduces_open(path):
     trace = {k: d[k] for k in d.files}
     name = str(trace.get("config", "default.yaml"))
     cfg = named_config({"default.yaml": "cfg1", "jconf_3.yaml": "cfg1"}.get(name, "cfg1"))
-    shipped = dict(akkt_gradient=0, ls_failure=0, inner_status=0, keep_multipliers=True)
+    shipped = dict(akkt_gradient=1, ls_failure=0, inner_status=0, keep_multipliers=True)
     rows = rank_variants(trace, cfg)
     table = "\n".join(f"{sc}  {sw}" for sc, sw in rows[:8])
     sc = score(trace, replay(trace, cfg, shipped))

@@ -76,3 +76,13 @@ def test_box_projection_known_answer():
     assert np.all(st["exit_status"] == 0)
     np.testing.assert_allclose(u[:, 0::2], np.tile(np.minimum(vref, cfg.lin_vel_max), (2, 1)), atol=2e-4)
     assert np.abs(u[:, 1::2]).max() <= 1e-12
+
+
+def test_nonfinite_cost_ends_the_solve():
+    """A penalty that overflows psi while the clamped controls stay finite: NotConvergedNotFiniteComputation (4).  OpEn
+    checks u only; the deviation is listed in include/nmpc_solver.h and the kernels do the same (tests/test_gpu_parity.py)."""
+    cfg = named_config("default")
+    P = synthetic_batch(cfg, 11, 16, 4242)
+    u, y, st = oracle_for(cfg).solve_batch(P, c0=np.full(16, 1e308), threads=4)
+    assert (st["exit_status"] == 4).sum() >= 12 and np.all(np.isfinite(u))
+    assert not np.any(np.isfinite(st["cost"][st["exit_status"] == 4]))
