@@ -23,6 +23,13 @@ constexpr int NZ = 20;         // reference configs/default.yaml:35
 constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
 constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
 constexpr int SEG_STRIDE = 6;  // doubles per reference segment in LDS
+// team mode of the hybrid kernel (nmpc_solve_hyb.h): four waves per workgroup; a wave without work of its own evaluates
+// line-search trials for its siblings.  Request = u, r, d by stage (3 x 24 pairs); one result area = three trials'
+// gradients by stage (3 x 24 pairs) + their psi values
+constexpr int TEAM_WAVES = 4;
+constexpr int TEAM_REQ_DOUBLES = 3 * 24 * 2;
+constexpr int TEAM_AREA_DOUBLES = 3 * 24 * 2 + 4;
+constexpr int TEAM_CTL_INTS = 64;
 
 // PANOC constants
 constexpr double GAMMA_L_COEFF = 0.95;
@@ -40,12 +47,13 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
-    int par;     // up to 16 parked solver scalars (hybrid kernel)
+    int par;     // up to 20 parked solver scalars (hybrid kernel)
     int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x dyn_stride per-stage ellipse data
     int dyn_stride;  // columns per (ellipse, field): 24 / 32 for the three- / two-point layouts, N rounded up to even for one point
+    int req;     // hybrid kernel, team mode: the line-search request of this wave's instance -- u, r, d as 3 x 24 (v, w) pairs by stage
     int vec;     // 7 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed, grad at u_k
     int rho;     // m
     int S, Y;    // m slots x N lanes x (v, w)
@@ -74,6 +82,8 @@ struct KArgs {
     int *pool;                 // [B]: parked instance ids in arrival order (-1: not yet published)
     unsigned int *pool_ctr;    // [0] next index to pop, [1] next index to push
     int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
+    int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
+    int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
     // eval kernel only
     const double *ev_c;
     const double *ev_y;
@@ -130,7 +140,7 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     int o = 0;
     mp.sc = o;  o += 20;
     mp.cw = o;  o += CW_NCOEF;
-    mp.par = o; o += 16;
+    mp.par = o; o += 20;
     mp.seg = o; o += SEG_STRIDE * (N + 5);
     mp.obs = o; o += 3 * (nobs + 4);
     const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
@@ -140,8 +150,9 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     // one point per wave keeps its solver vectors in registers and needs ellipse columns for the real stages only: without
     // the 64-column tables a 40-stage slice is 21.6 KB instead of 32.9 KB -- 7 resident waves per CU instead of 4
     mp.dyn_stride = P == 64 ? ((N + 1) & ~1) : (P == 20 ? 24 : P);
-    mp.dyn = o; o += NDYN_MAX * 6 * (P == 64 ? mp.dyn_stride : cols);
+    mp.dyn = o; o += NDYN_MAX * 6 * mp.dyn_stride;
     o = (o + 1) & ~1;
+    mp.req = o; o += P == 20 ? TEAM_REQ_DOUBLES : 0;
     mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
     o = (o + 1) & ~1;                                 // 16-byte alignment for the double2 arrays
     const int ring = P == 20 ? N + 1 : N;             // (+1: the hybrid kernel keeps an all-zero column per slot)
@@ -999,8 +1010,11 @@ struct nmpc_handle {
     bool shape_n40;        // ... == ShapeN40
     int grid_cap;          // resident waves the launch is sized for
     double last_ms;        // kernel time of the last host-path batch
+    size_t team_lds;       // hybrid kernel: dynamic LDS bytes of one workgroup (four slices + control block)
     unsigned int *d_queue;
     int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
+    int team_owners_forced;    // experiments (NMPC_TEAM_OWNERS): waves per workgroup that take instances, 0 = automatic
+    int team_help;             // experiments (NMPC_TEAM_HELP=0): helpers never asked
     double *d_park;            // parked solver states, allocated on first use
     int *d_pool;
     unsigned int *d_pool_ctr;
@@ -1091,6 +1105,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->park_min = 500; h->park_depth = 8;
     if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // tuning knobs; 0 switches migration off
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
+    h->team_owners_forced = 0;
+    h->team_help = 1;
+    if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
+    if (const char *env = getenv("NMPC_TEAM_OWNERS")) { const int v = atoi(env); if (v >= 1 && v <= nmpc::TEAM_WAVES) h->team_owners_forced = v; }
     h->d_order = nullptr;
     h->d_cls = nullptr;
     h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
@@ -1105,12 +1123,28 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * (64 / h->P);   // eval kernel: one slice per group
     if (lds_bytes > 160 * 1024) { nmpc_free(h); return NMPC_ERR_BAD_PROBLEM; }
     // the solve kernels use one LDS slice per wave; resident waves per CU are bounded by LDS and by
-    // the register budget (2 waves per SIMD)
-    int per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
-    if (per_cu > 8) per_cu = 8;
+    // the register budget (2 waves per SIMD).  The hybrid kernel runs workgroups of four waves (teams).
+    int per_cu;
+    if (h->P == 20) {
+        const size_t wg_bytes = nmpc::TEAM_WAVES * (size_t)h->map.total * sizeof(double) + nmpc::TEAM_CTL_INTS * sizeof(int);
+        int wgs = (int)((160 * 1024) / wg_bytes);
+        if (wgs > 2) wgs = 2;
+        if (wgs < 1) { nmpc_free(h); return NMPC_ERR_BAD_PROBLEM; }
+        per_cu = wgs * nmpc::TEAM_WAVES;
+        h->team_lds = wg_bytes;
+        // more than 64 KB of dynamic LDS per workgroup has to be asked for
+        const int bytes = (int)wg_bytes;
+        e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
+    } else {
+        per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
+        if (per_cu > 8) per_cu = 8;
+    }
     if (const char *env = getenv("NMPC_WAVES_PER_CU")) {       // tuning knob (experiments only)
         const int v = atoi(env);
-        if (v >= 1 && v <= per_cu) per_cu = v;
+        if (v >= 1 && v <= per_cu && (h->P != 20 || v % nmpc::TEAM_WAVES == 0)) per_cu = v;
     }
     if (per_cu < 1) per_cu = 1;
     h->grid_cap = prop.multiProcessorCount * per_cu;
@@ -1166,7 +1200,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), s));
     // one instance per wave: N_hor <= 20 evaluates three query points per pass (hybrid / tri layouts),
     // 20 < N_hor <= 32 two (dual kernel), longer horizons one, with the whole wave as one group
-    const int grid = B < h->grid_cap ? B : h->grid_cap;
+    const int grid = B < h->grid_cap ? B : h->grid_cap;          // waves that take instances
     if (B > grid) {        // more instances than resident waves: hand the hard-looking ones out first
         hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
         hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
@@ -1188,9 +1222,27 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
-    if (h->P == 20 && h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20 && h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(grid), dim3(64), lds, s, a);
+    if (h->P == 20) {
+        // teams of four waves.  With fewer instances than workgroups fit on the chip every instance gets a workgroup of its
+        // own (one wave solves, three help from the first iteration on: the small-batch / latency mode); otherwise as many
+        // waves per workgroup take instances as it needs for all of them to start at once, up to all four.
+        const int max_wgs = h->grid_cap / nmpc::TEAM_WAVES;
+        int owners = (B + max_wgs - 1) / max_wgs;
+        if (owners > nmpc::TEAM_WAVES) owners = nmpc::TEAM_WAVES;
+        if (h->team_owners_forced > 0) owners = h->team_owners_forced;
+        int wgs = (grid + owners - 1) / owners;
+        if (wgs > max_wgs) wgs = max_wgs;
+        a.team_owners = owners;
+        a.team_help = h->team_help;
+#ifdef NMPC_PROFILE
+        const size_t tlds = lds;
+#else
+        const size_t tlds = h->team_lds;
+#endif
+        if (h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
+        else if (h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
+        else hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
+    }
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else if (h->shape_n40) hipLaunchKernelGGL((nmpc::nmpc_solve_kernel<64, nmpc::ShapeN40>), dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);

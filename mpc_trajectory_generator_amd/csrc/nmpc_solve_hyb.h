@@ -23,9 +23,28 @@
 // small: u, y, the previous gradient and a dozen scalars) and pushed to a pool; favoured waves look into the
 // pool before they take new work from the queue and resume it.  The arithmetic does not change, only where
 // an instance runs; the pusher itself falls back to the pool once the queue is exhausted, so nothing is lost.
+//
+// Teams.  A workgroup is FOUR such waves (one per SIMD of the CU), each with its own LDS slice and its own instances.  A
+// batch ends when its slowest instance does, and long before that most waves have run out of work.  A wave without work
+// of its own therefore stays and HELPS its siblings: the owner of an instance publishes (u, r, d) of the iteration it
+// is starting in its LDS slice, idle waves of the workgroup claim the line-search trials tau = 2^-2 .. 2^-10 in triples
+// (the owner itself evaluates u_bar, tau = 1 and tau = 1/2 in the same pass), evaluate psi, grad psi at them out of the
+// owner's tables and leave the results in LDS; the owner consumes trials strictly in order, exactly as before, so the
+// first accepted one ends the iteration and everything after it is discarded -- same bits, same counters, but an
+// iteration whose line search goes deep costs the owner ONE pass instead of up to four.  With fewer instances than a
+// quarter of the resident waves the launch gives every instance a whole workgroup from the start (opengen's own call
+// pattern, B = 1, src/path_generator.py:385: the latency mode).  Protocol (all in LDS, workgroup scope): claim word per
+// owner = (request sequence << 8 | next unclaimed task), taken by compare-and-swap; one done flag per (owner, task,
+// helper) written by that helper only, so a late writer of a stale request can never overwrite a current flag.
 #pragma once
 
 namespace nmpc {
+
+typedef __attribute__((address_space(3))) int lds_int;
+// control block of a workgroup, after the four slices
+enum { CTL_OWNERS = 0, CTL_HELPERS = 1, CTL_CLAIM = 4, CTL_DONE = 8 };     // done: [owner][task][helper]
+__device__ __forceinline__ int ctl_load(lds_int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ctl_store(lds_int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // a query point's scalar (psi): every lane of the point's row holds it; rows 0..2 are points 0..2
 __device__ __forceinline__ double point_scalar(double v, int k)
@@ -76,13 +95,16 @@ __device__ __forceinline__ void pool_push(const KArgs &a, int inst)
 }
 
 template <class SH>
-__global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
+__global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArgs a)
 {
     constexpr int PE = 20;                      // evaluation layout: three lane groups (nmpc_device.h)
     constexpr int P = 32, COLS = 32;            // state layout: stage t at lane t of both 32-lane halves
     extern __shared__ double lds[];
-    lds_double *L = (lds_double *)lds;
-    const int lane = threadIdx.x, h = lane >> 5, t = lane & 31;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave of the team
+    const int slice = the_map<SH, PE>(a).total;
+    lds_double *L = (lds_double *)lds + wid * slice;
+    lds_int *ctl = (lds_int *)((lds_double *)lds + TEAM_WAVES * slice);
+    const int lane = threadIdx.x & 63, h = lane >> 5, t = lane & 31;
     const int q = lay_group<PE>(lane), te = lay_stage<PE>(lane);
     const int N = shape_N<SH>(a), m = a.op.lbfgs_memory;
     const bool in = t < N, ina = in;            // state layout: lanes beyond the horizon hold zeros
@@ -110,7 +132,10 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
     lds_double2 *Ly = (lds_double2 *)(L + mp.vec) + 4 * COLS + te;        // multipliers y (read by every evaluation)
     lds_double *Lvr = L + mp.vec + 2 * 5 * COLS + te;                     // reference speed of this stage
     if (lane < m) { LS[lane * NS + N] = dbl2{0.0, 0.0}; LY[lane * NS + N] = dbl2{0.0, 0.0}; }
-    NMPC_WAVE_SYNC();
+    if (threadIdx.x < TEAM_CTL_INTS) ctl[threadIdx.x] = threadIdx.x == CTL_OWNERS ? a.team_owners : 0;
+    __syncthreads();
+    lds_double2 *Lreq = (lds_double2 *)(L + mp.req);      // this wave's request: u | r | d by stage
+    unsigned team_seq = 0;                                // sequence number of this wave's requests
     const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
     const unsigned max_inner = (unsigned)a.op.max_inner;
     const unsigned budget = (unsigned)a.op.max_total_inner;     // 0 = off
@@ -128,6 +153,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
 #define pk_gr Lpar[12]          /* <grad psi, r> of the current iterate: summed together with ||r||^2, used by the Lipschitz test */
+    /* Lpar[13], Lpar[14]: first start (100 MHz clock) and migration count; Lpar[15], Lpar[16]: c and 1 / max(c, 1) of the request */
 
 
     // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
@@ -138,15 +164,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
     // first round: the queue's head -- the instances that look hardest -- goes to the favoured wave slots; the other
     // waves hold back until half of the resident waves have fetched.  Bounded by the constant 100 MHz clock (40 us),
     // and skipped when the queue holds barely more than one round (nothing to gain from ordering the first fetches)
-    if (a.order && unfavoured && a.park_min > 0 && a.B >= (int)gridDim.x + (int)(gridDim.x >> 2)) {
-        const unsigned want = gridDim.x / 2;
+    const int n_waves = (int)gridDim.x * TEAM_WAVES;
+    if (a.order && unfavoured && a.park_min > 0 && a.B >= n_waves + (n_waves >> 2)) {
+        const unsigned want = (unsigned)n_waves / 2;
         const long long t_hold = (long long)__builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
                (long long)__builtin_amdgcn_s_memrealtime() - t_hold < 4000)
             __builtin_amdgcn_s_sleep(8);
     }
 
-    for (;;) {
+    for (; wid < a.team_owners;) {
         // ------------------------------------------------------------------ next instance: parked long-runners first
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
@@ -230,6 +257,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
+        bool posted = false;                      // a request of the current iteration is open for the helpers
 #ifdef NMPC_PROFILE
         { extern __shared__ long long nmpc_prof_lds[]; if (lane < 16) nmpc_prof_lds[4096 + lane] = 0; }
         long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
@@ -241,6 +269,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
             if (f_back) {
                 f_back = false;
+                if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }      // speculation discarded
                 lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
                 fbe_ok = false;
                 pk_Lc *= 2.0; gamma /= 2.0;
@@ -404,6 +433,16 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                     yqv = fma(-0.5, dv, fma(-0.5, rv, uv));               // Y: u+(tau = 1/2)
                     yqw = fma(-0.5, dw, fma(-0.5, rw, uw));
                     need_grad = true; state = D_ITER;
+                    // team: idle waves of this workgroup evaluate the trials tau = 2^-2 .. 2^-10 of this direction meanwhile
+                    if (a.team_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
+                        if (in && h == 0) { Lreq[t] = dbl2{uv, uw}; Lreq[24 + t] = dbl2{rv, rw}; Lreq[48 + t] = dbl2{dv, dw}; }
+                        if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; }
+                        team_seq = team_seq >= 0xffff0u ? 1u : team_seq + 1u;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, (int)(team_seq << 8));
+                        posted = true;
+                    }
                 }
             }
             // ---------------------------------------------------------------- the inner solver returned
@@ -468,12 +507,13 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
 #endif
             const double psiA = point_scalar(psi, 0), psiB = point_scalar(psi, 1), psiC = point_scalar(psi, 2);
             // one trial of the current direction: psi, grad psi were evaluated by query point K at step tau
-#define NMPC_TAKE_TRIAL(PSI, SRC)                                                      \
+#define NMPC_TAKE_TRIAL(PSI, SRC) NMPC_TAKE_TRIAL_(PSI, NMPC_FETCH_GRAD((SRC), gv, gw))
+#define NMPC_TAKE_TRIAL_(PSI, FETCH)                                                   \
             do {                                                                       \
                 n_grad++;                                                              \
                 *Lq = dbl2{gv, gw};                  /* cache_previous_gradient */     \
                 cost = (PSI);                                                          \
-                NMPC_FETCH_GRAD((SRC), gv, gw);                                        \
+                FETCH;                                                                 \
                 const double omt_ = 1.0 - tau;                                         \
                 pv = fma(-tau, dv, fma(-omt_, rv, uv));                                \
                 pw = fma(-tau, dw, fma(-omt_, rw, uw));                                \
@@ -534,7 +574,48 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
                         if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
                         NMPC_TAKE_TRIAL(psiB, src1);                     // tau = 1
                         if (rejected) NMPC_TAKE_TRIAL(psiC, src2);       // tau = 1/2
+                        if (posted) {
+                            // tasks 0..2 of the request hold trials ls_n = 2 + 3k .. 4 + 3k.  A task a helper has claimed is
+                            // waited for and consumed in order; the first one nobody has claimed is closed (with everything
+                            // after it) and this wave goes on by itself, as it would without a team.
+                            for (int k = 0; k < 3 && rejected; ++k) {
+                                int hid = -1;
+                                if (lane == 0) {
+                                    lds_int *cl = ctl + CTL_CLAIM + wid;
+                                    bool served = false;
+                                    for (;;) {
+                                        int v = ctl_load(cl);
+                                        if ((v & 0xff) > k) { served = true; break; }
+                                        if (__hip_atomic_compare_exchange_strong(cl, &v, (int)(team_seq << 8) | 3, __ATOMIC_RELAXED,
+                                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                                    }
+                                    if (served) {
+                                        lds_int *dn = ctl + CTL_DONE + (wid * 3 + k) * TEAM_WAVES;
+                                        for (;;) {
+#pragma unroll
+                                            for (int w2 = 0; w2 < TEAM_WAVES; ++w2) if (ctl_load(dn + w2) == (int)team_seq) hid = w2;
+                                            if (hid >= 0) break;
+                                            __builtin_amdgcn_s_sleep(1);
+                                        }
+                                    }
+                                }
+                                hid = __builtin_amdgcn_readfirstlane(hid);
+                                if (hid < 0) break;
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                n_pass++;                                // the pass these three trials would have cost this wave
+                                const lds_double *ar = (const lds_double *)lds + hid * slice + (wid * 3 + k) * TEAM_AREA_DOUBLES;
+                                const lds_double2 *ag = (const lds_double2 *)ar + (in ? t : 0);
+#define NMPC_AREA_GRAD(J) do { const dbl2 g_ = ag[24 * (J)]; gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0; } while (0)
+                                NMPC_TAKE_TRIAL_(ar[2 * 72 + 0], NMPC_AREA_GRAD(0));
+                                if (rejected) NMPC_TAKE_TRIAL_(ar[2 * 72 + 1], NMPC_AREA_GRAD(1));
+                                if (rejected) NMPC_TAKE_TRIAL_(ar[2 * 72 + 2], NMPC_AREA_GRAD(2));
+#undef NMPC_AREA_GRAD
+                            }
+                            posted = false;
+                            if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0);      // the request is over
+                        }
                         if (rejected) f_trials = true;
+                        else if (exhausted) f_fb = true;
                         else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
                     }
                 }
@@ -661,6 +742,55 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_hyb_kernel(KArgs a)
         }
         if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
+    }
+
+    // ====================================================================== no work of its own (any more): help the team
+    // This wave's slice is free now; it holds the result areas, one per (owner, task).
+    if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
+    if (lane == 0) {
+        if (wid < a.team_owners) __hip_atomic_fetch_add(ctl + CTL_OWNERS, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(ctl + CTL_HELPERS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    for (;;) {
+        if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;
+        // claim the next open task of some sibling's request
+        int got = -1;
+        if (lane == 0) {
+            for (int w = 0; w < TEAM_WAVES && got < 0; ++w) {
+                if (w == wid) continue;
+                int v = ctl_load(ctl + CTL_CLAIM + w);
+                if ((v >> 8) != 0 && (v & 0xff) < 3 &&
+                    __hip_atomic_compare_exchange_strong(ctl + CTL_CLAIM + w, &v, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP))
+                    got = (w << 28) | (v & 0x0fffffff);
+            }
+        }
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got < 0) { __builtin_amdgcn_s_sleep(2); continue; }
+        const int w = got >> 28, k = got & 0xff;
+        const int seq = (got & 0x0fffffff) >> 8;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the owner's slice: tables of its instance, multipliers, reference speeds, the request
+        lds_double *Lw = (lds_double *)lds + w * slice;
+        const lds_double2 *rq = (const lds_double2 *)(Lw + mp.req) + te;
+        const dbl2 u_ = rq[0], r_ = rq[24], d_ = rq[48];
+        const double c_w = Lw[mp.par + 15], cbar_w = Lw[mp.par + 16];
+        const dbl2 y_w = ((const lds_double2 *)(Lw + mp.vec) + 4 * COLS)[te];
+        const double vref_w = Lw[mp.vec + 2 * 5 * COLS + te];
+        DynStage dyn_w;
+        dyn_w.col = Lw + mp.dyn + te;
+        dyn_w.stride = lay_cols<PE>();
+        // point q of this pass is trial ls_n = 2 + 3k + q: tau = 2^-ls_n, u+ = u - (1 - tau) r - tau d
+        const double tau_w = __hiloint2double((1023 - (2 + 3 * k + q)) << 20, 0), omt_w = 1.0 - tau_w;
+        const double zv = fma(-tau_w, d_.x, fma(-omt_w, r_.x, u_.x)), zw = fma(-tau_w, d_.y, fma(-omt_w, r_.y, u_.y));
+        double psi, pen, egv = 0, egw = 0, eav, eaw;
+        eval_psi<PE, SH>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw);
+        lds_double *ar = L + (w * 3 + k) * TEAM_AREA_DOUBLES;
+        ((lds_double2 *)ar)[24 * q + te] = dbl2{egv, egw};
+        if (te == 0) ar[2 * 72 + q] = psi;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) ctl_store(ctl + CTL_DONE + (w * 3 + k) * TEAM_WAVES + wid, seq);
     }
 }
 #undef pk_eps_nu

@@ -449,3 +449,45 @@ def test_per_instance_solve_time(solvers, name, B, monkeypatch):
         work = st["reserved"].astype(np.float64)
         assert np.corrcoef(work, t)[0, 1] > 0.8
         assert t[np.argmax(work)] > np.median(t)
+
+
+@pytest.mark.parametrize("env", [{"NMPC_TEAM_HELP": "0"}, {"NMPC_TEAM_OWNERS": "4"}, {"NMPC_TEAM_OWNERS": "2"},
+                                 {"NMPC_TEAM_OWNERS": "1"}, {}],
+                         ids=["no-help", "4-owners", "2-owners", "1-owner", "auto"])
+@pytest.mark.parametrize("name,B", [("cfg1", 160), ("cfg3", 40), ("cfg4", 40), ("n17", 24)])
+def test_team_modes_same_bits(monkeypatch, name, B, env):
+    """The teams of the hybrid kernel (nmpc_solve_hyb.h): whether nobody helps, helpers appear only as the waves of a
+    workgroup run out of work (4 owners), or every instance has helpers from its first iteration (1 owner, the
+    small-batch mode), the owner consumes line-search trials in the sequential order -- the oracle's bits and counters,
+    including the pass count of the three-point schedule."""
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = load_config(N_hor=17, Nobs=4, Ndynobs=1) if name == "n17" else named_config(name)
+    P = synthetic_batch(cfg, 11, B, 2718, synthetic_circles=(name == "cfg3"), random_dyn=(name in ("cfg4", "n17")))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = BatchSolver(cfg, max_batch=B)
+    try:
+        gpu = s.solve(P)
+        gpu2 = s.solve(P, u0=gpu[0], y0=gpu[1])            # a warm start: short solves, helpers racing with fast owners
+    finally:
+        s.close()
+    o = oracle_for(cfg)
+    cpu = o.solve_batch(P, threads=8)
+    assert_same_solution(gpu, cpu)
+    assert np.array_equal(gpu[2]["reserved"], cpu[2]["reserved"])
+    assert_same_solution(gpu2, o.solve_batch(P, u0=cpu[0], y0=cpu[1], threads=8))
+
+
+def test_team_switches_and_budget_bit_exact(monkeypatch):
+    """Line-search exhaustion (ls_failure = 1: the eleventh trial comes from a helper's result area), the per-trial
+    AKKT gradient cache and the iteration budget, with helpers from the first iteration on."""
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = named_config("cfg1")
+    P = synthetic_batch(cfg, 11, 48, 797)
+    for opts in (dict(ls_failure=1), dict(akkt_gradient=0, ls_failure=1), dict(max_total_inner=300), dict(lbfgs_memory=3)):
+        s = BatchSolver(cfg, max_batch=64, **opts)
+        try:
+            assert_same_solution(s.solve(P), oracle_for(cfg, **s.oracle_opts()).solve_batch(P, threads=8))
+        finally:
+            s.close()
