@@ -45,6 +45,7 @@ typedef __attribute__((address_space(3))) int lds_int;
 enum { CTL_OWNERS = 0, CTL_HELPERS = 1, CTL_CLAIM = 4, CTL_DONE = 8 };     // done: [owner][task][helper]
 __device__ __forceinline__ int ctl_load(lds_int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ctl_store(lds_int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int ctl_add(lds_int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // a query point's scalar (psi): every lane of the point's row holds it; rows 0..2 are points 0..2
 __device__ __forceinline__ double point_scalar(double v, int k)
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
 #define pk_gr Lpar[12]          /* <grad psi, r> of the current iterate: summed together with ||r||^2, used by the Lipschitz test */
-    /* Lpar[13], Lpar[14]: first start (100 MHz clock) and migration count; Lpar[15], Lpar[16]: c and 1 / max(c, 1) of the request */
+    /* Lpar[13], Lpar[14]: first start (100 MHz clock) and migration count; Lpar[15..17]: c, 1 / max(c, 1) and gamma of the request */
 
 
     // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
@@ -173,21 +174,26 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             __builtin_amdgcn_s_sleep(8);
     }
 
+    // A wave is first the OWNER of the instances it takes from the queue (the loop right below); once there is nothing left
+    // for it -- or from the start, for the waves beyond team_owners in the small-batch mode -- it is a HELPER of its siblings
+    // (the loop at the end) until the last of them has finished.
+    bool yielded = false;                       // the previous instance stepped aside for a fresh one: take it from the queue
     for (; wid < a.team_owners;) {
         // ------------------------------------------------------------------ next instance: parked long-runners first
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
         if (lane == 0) {
-            if (a.park_min > 0 && !unfavoured) { fetched = pool_pop(a); from_pool = fetched >= 0; }
+            if (a.park_min > 0 && !unfavoured && !yielded) { fetched = pool_pop(a); from_pool = fetched >= 0; }
             if (fetched < 0) {
                 const unsigned nxt = atomicAdd(a.queue, 1u);
                 if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
                 else if (a.park_min > 0) { fetched = pool_pop(a); from_pool = fetched >= 0; }
             }
         }
+        yielded = false;
         const int inst = __builtin_amdgcn_readfirstlane(fetched);
         const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
-        if (inst < 0) break;
+        if (inst < 0) break;     // nothing left for this wave: a helper from now on
 
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
         // (experiments, scripts/slot_probe.py: first start and migration count travel with the instance; parked in LDS)
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
         bool parked = false;
+        int pool_len = 0;
         if (resumed) {                            // parked scalars
             const double *pks = a.park + (size_t)inst * PS + 6 * N;
             pen_c = pks[0];
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
             Lpar[13] = pks[13]; Lpar[14] = pks[14] + 1.0;
         }
+        const unsigned n_pass0 = n_pass;          // passes before this leg: the quantum of (b) below counts from here
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
@@ -436,7 +444,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     // team: idle waves of this workgroup evaluate the trials tau = 2^-2 .. 2^-10 of this direction meanwhile
                     if (a.team_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
                         if (in && h == 0) { Lreq[t] = dbl2{uv, uw}; Lreq[24 + t] = dbl2{rv, rw}; Lreq[48 + t] = dbl2{dv, dw}; }
-                        if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; }
+                        if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; Lpar[17] = gamma; }
                         team_seq = team_seq >= 0xffff0u ? 1u : team_seq + 1u;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __builtin_amdgcn_wave_barrier();
@@ -578,6 +586,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                             // tasks 0..2 of the request hold trials ls_n = 2 + 3k .. 4 + 3k.  A task a helper has claimed is
                             // waited for and consumed in order; the first one nobody has claimed is closed (with everything
                             // after it) and this wave goes on by itself, as it would without a team.
+                            const lds_double2 *prev_ag = nullptr;        // gradient of the last trial a helper's area rejected
                             for (int k = 0; k < 3 && rejected; ++k) {
                                 int hid = -1;
                                 if (lane == 0) {
@@ -603,13 +612,40 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                 if (hid < 0) break;
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                                 n_pass++;                                // the pass these three trials would have cost this wave
+                                // The helper has formed each trial's envelope value too (same canonical sums), so the sequential
+                                // decision over its three trials is three comparisons; only the trial the search stops at -- accepted,
+                                // or the eleventh -- is loaded into the solver state.
                                 const lds_double *ar = (const lds_double *)lds + hid * slice + (wid * 3 + k) * TEAM_AREA_DOUBLES;
                                 const lds_double2 *ag = (const lds_double2 *)ar + (in ? t : 0);
-#define NMPC_AREA_GRAD(J) do { const dbl2 g_ = ag[24 * (J)]; gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0; } while (0)
-                                NMPC_TAKE_TRIAL_(ar[2 * 72 + 0], NMPC_AREA_GRAD(0));
-                                if (rejected) NMPC_TAKE_TRIAL_(ar[2 * 72 + 1], NMPC_AREA_GRAD(1));
-                                if (rejected) NMPC_TAKE_TRIAL_(ar[2 * 72 + 2], NMPC_AREA_GRAD(2));
-#undef NMPC_AREA_GRAD
+                                int jstop = 3;
+#pragma unroll
+                                for (int j = 2; j >= 0; --j) {
+                                    const bool rej_j = __any(ar[2 * 72 + 4 + j] > rhs_ls) && ls_n + j < MAX_LINESEARCH_ITERATIONS;
+                                    if (!rej_j) jstop = j;               // ends as the FIRST trial that is not rejected
+                                }
+                                if (jstop == 3) {                        // all three rejected: on to the next task
+                                    n_grad += 3; ls_n += 3; tau *= 0.125;
+                                    prev_ag = ag + 24 * 2;
+                                } else {
+                                    n_grad += (unsigned)jstop + 1u; ls_n += jstop;
+                                    tau *= jstop == 0 ? 1.0 : (jstop == 1 ? 0.5 : 0.25);
+                                    // cache_previous_gradient: the gradient of the trial before the one that stops the search
+                                    if (jstop > 0) prev_ag = ag + 24 * (jstop - 1);
+                                    if (prev_ag) { const dbl2 g_ = *prev_ag; *Lq = dbl2{in ? g_.x : 0.0, in ? g_.y : 0.0}; }
+                                    else *Lq = dbl2{gv, gw};
+                                    cost = ar[2 * 72 + jstop];
+                                    { const dbl2 g_ = ag[24 * jstop]; gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0; }
+                                    const double omt_ = 1.0 - tau;
+                                    pv = fma(-tau, dv, fma(-omt_, rv, uv));
+                                    pw = fma(-tau, dw, fma(-omt_, rw, uw));
+                                    NMPC_HALF_STEP(pv, pw);
+                                    lhs = ar[2 * 72 + 4 + jstop];
+                                    exhausted = __any(lhs > rhs_ls) && a.op.ls_failure == 1;      // (only the eleventh trial can stop the search while bad)
+                                    rejected = false;
+                                }
+                            }
+                            if (rejected && prev_ag) {                   // going on alone: the state holds the last rejected trial's gradient
+                                const dbl2 g_ = *prev_ag; gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0;
                             }
                             posted = false;
                             if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0);      // the request is over
@@ -661,12 +697,19 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
                     else if (timed_out) { final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; running = false; nu--; }      // (the report adds the one back)
-                    else if (a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min &&
+                    else if (a.park_min > 0 && n_pass >= (unsigned)a.park_min &&
                              __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.B &&
-                             __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                                                                  __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) < a.park_depth) {
-                        // a long-runner on the unfavoured wave slot, favoured waves will still come back for work
-                        // and few instances are waiting for them already: hand it over at this outer-iteration boundary
+                             (pool_len = __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                                                  __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))),
+                              (unfavoured && pool_len < a.park_depth) ||
+                              (a.yield_after > 0 && n_pass - n_pass0 >= (unsigned)a.yield_after && pool_len < a.yield_depth))) {
+                        // (a) a long-runner on the unfavoured wave slot, favoured waves will still come back for work and few
+                        // instances are waiting for them already: hand it over at this outer-iteration boundary;
+                        // (b) any long-runner that has had its quantum while instances nobody has looked at yet are still
+                        // queueing: it steps aside for one of them (this wave takes its next instance from the queue) and is
+                        // resumed by the next favoured wave that becomes free -- round robin at outer-iteration boundaries, so
+                        // that hard instances sitting far back in the queue are found and started while the early ones run
+                        yielded = !(unfavoured && pool_len < a.park_depth);
                         parked = true; running = false;
                     } else f_start = true;
                 }
@@ -744,12 +787,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
     }
 
-    // ====================================================================== no work of its own (any more): help the team
+    // ====================================================================== helper: no work of its own (any more)
     // This wave's slice is free now; it holds the result areas, one per (owner, task).
     if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
     if (lane == 0) {
-        if (wid < a.team_owners) __hip_atomic_fetch_add(ctl + CTL_OWNERS, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(ctl + CTL_HELPERS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
+        ctl_add(ctl + CTL_HELPERS, 1);
     }
     for (;;) {
         if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;
@@ -785,9 +828,17 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         const double zv = fma(-tau_w, d_.x, fma(-omt_w, r_.x, u_.x)), zw = fma(-tau_w, d_.y, fma(-omt_w, r_.y, u_.y));
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         eval_psi<PE, SH>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw);
+        // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
+        // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute
+        const double gam_w = Lw[mp.par + 17];
+        const double s1_ = fma(-gam_w, egv, zv), s2_ = fma(-gam_w, egw, zw);
+        const double e1_ = s1_ - (inea ? clampd(s1_, vmin, vmax) : s1_), e2_ = s2_ - (inea ? clampd(s2_, -wmax, wmax) : s2_);
+        const double dist2_ = group_sum<PE>(inea ? fma(e1_, e1_, e2_ * e2_) : 0.0, lane);
+        const double gg_ = group_sum<PE>(inea ? fma(egv, egv, egw * egw) : 0.0, lane);
+        const double lhs_ = psi - (0.5 * gam_w) * gg_ + (0.5 * dist2_) / gam_w;
         lds_double *ar = L + (w * 3 + k) * TEAM_AREA_DOUBLES;
         ((lds_double2 *)ar)[24 * q + te] = dbl2{egv, egw};
-        if (te == 0) ar[2 * 72 + q] = psi;
+        if (te == 0) { ar[2 * 72 + q] = psi; ar[2 * 72 + 4 + q] = lhs_; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) ctl_store(ctl + CTL_DONE + (w * 3 + k) * TEAM_WAVES + wid, seq);
