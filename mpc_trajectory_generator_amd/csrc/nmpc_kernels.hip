@@ -78,7 +78,6 @@ struct KArgs {
     // migration of long-running instances to the SIMD's favoured wave slot (nmpc_solve_hyb.h), 0 = off
     int park_min;              // passes after which an instance on an unfavoured wave is parked at an outer-iteration boundary
     int park_depth;            // ... unless this many parked instances are already waiting for a favoured wave
-    int yield_after, yield_depth;  // a long-runner steps aside for a fresh instance after this many passes of a leg (0 = never) / pool limit
     double *park;              // [B][park_stride]: parked solver state
     int *pool;                 // [B]: parked instance ids in arrival order (-1: not yet published)
     unsigned int *pool_ctr;    // [0] next index to pop, [1] next index to push
@@ -1014,7 +1013,6 @@ struct nmpc_handle {
     size_t team_lds;       // hybrid kernel: dynamic LDS bytes of one workgroup (four slices + control block)
     unsigned int *d_queue;
     int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
-    int yield_after, yield_depth;
     int team_owners_forced;    // experiments (NMPC_TEAM_OWNERS): waves per workgroup that take instances, 0 = automatic
     int team_help;             // experiments (NMPC_TEAM_HELP=0): helpers never asked
     double *d_park;            // parked solver states, allocated on first use
@@ -1107,9 +1105,6 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->park_min = 500; h->park_depth = 8;
     if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // tuning knobs; 0 switches migration off
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
-    h->yield_after = 0; h->yield_depth = 256;
-    if (const char *env = getenv("NMPC_YIELD_AFTER")) h->yield_after = atoi(env);
-    if (const char *env = getenv("NMPC_YIELD_DEPTH")) h->yield_depth = atoi(env);
     h->team_owners_forced = 0;
     h->team_help = 1;
     if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
@@ -1219,7 +1214,6 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
             HIP_TRY(h, hipMemsetAsync(h->d_pool, 0xFF, (size_t)B * sizeof(int), s));
             HIP_TRY(h, hipMemsetAsync(h->d_pool_ctr, 0, 2 * sizeof(unsigned int), s));
             a.park_min = h->park_min; a.park_depth = h->park_depth;
-            a.yield_after = h->yield_after; a.yield_depth = h->yield_depth;
             a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr;
         }
     }

@@ -177,20 +177,18 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // A wave is first the OWNER of the instances it takes from the queue (the loop right below); once there is nothing left
     // for it -- or from the start, for the waves beyond team_owners in the small-batch mode -- it is a HELPER of its siblings
     // (the loop at the end) until the last of them has finished.
-    bool yielded = false;                       // the previous instance stepped aside for a fresh one: take it from the queue
     for (; wid < a.team_owners;) {
         // ------------------------------------------------------------------ next instance: parked long-runners first
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
         if (lane == 0) {
-            if (a.park_min > 0 && !unfavoured && !yielded) { fetched = pool_pop(a); from_pool = fetched >= 0; }
+            if (a.park_min > 0 && !unfavoured) { fetched = pool_pop(a); from_pool = fetched >= 0; }
             if (fetched < 0) {
                 const unsigned nxt = atomicAdd(a.queue, 1u);
                 if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
                 else if (a.park_min > 0) { fetched = pool_pop(a); from_pool = fetched >= 0; }
             }
         }
-        yielded = false;
         const int inst = __builtin_amdgcn_readfirstlane(fetched);
         const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
         if (inst < 0) break;     // nothing left for this wave: a helper from now on
@@ -250,7 +248,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
         bool parked = false;
-        int pool_len = 0;
         if (resumed) {                            // parked scalars
             const double *pks = a.park + (size_t)inst * PS + 6 * N;
             pen_c = pks[0];
@@ -260,7 +257,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
             Lpar[13] = pks[13]; Lpar[14] = pks[14] + 1.0;
         }
-        const unsigned n_pass0 = n_pass;          // passes before this leg: the quantum of (b) below counts from here
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
@@ -697,19 +693,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
                     else if (timed_out) { final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; running = false; nu--; }      // (the report adds the one back)
-                    else if (a.park_min > 0 && n_pass >= (unsigned)a.park_min &&
+                    else if (a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min &&
                              __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.B &&
-                             (pool_len = __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                                                                  __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))),
-                              (unfavoured && pool_len < a.park_depth) ||
-                              (a.yield_after > 0 && n_pass - n_pass0 >= (unsigned)a.yield_after && pool_len < a.yield_depth))) {
-                        // (a) a long-runner on the unfavoured wave slot, favoured waves will still come back for work and few
-                        // instances are waiting for them already: hand it over at this outer-iteration boundary;
-                        // (b) any long-runner that has had its quantum while instances nobody has looked at yet are still
-                        // queueing: it steps aside for one of them (this wave takes its next instance from the queue) and is
-                        // resumed by the next favoured wave that becomes free -- round robin at outer-iteration boundaries, so
-                        // that hard instances sitting far back in the queue are found and started while the early ones run
-                        yielded = !(unfavoured && pool_len < a.park_depth);
+                             __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                                                  __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) < a.park_depth) {
+                        // a long-runner on the unfavoured wave slot, favoured waves will still come back for work
+                        // and few instances are waiting for them already: hand it over at this outer-iteration boundary
                         parked = true; running = false;
                     } else f_start = true;
                 }
