@@ -896,6 +896,7 @@ __host__ __device__ inline int park_stride(int N) { return 6 * N + 16; }
 }
 #include "nmpc_solve_dual.h"
 #include "nmpc_solve_hyb.h"
+#include "nmpc_solve_hyb2.h"
 #include "nmpc_loop.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -1004,7 +1005,7 @@ struct nmpc_handle {
     int max_batch;
     bool alive;
     LdsMap map;
-    int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one)
+    int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one; 40: three points, two stages per lane)
     bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
     bool shape_nobs50;     // ... == ShapeNobs50
     bool shape_n40;        // ... == ShapeN40
@@ -1087,7 +1088,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         return NMPC_ERR_NO_DEVICE;
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true; h->last_ms = 0.0;
-    h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : 64);
+    h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : (pb->N <= 40 ? 40 : 64));
     if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments / cross-checks: force the two-point layout
         if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
     }
@@ -1099,7 +1100,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (const char *env = getenv("NMPC_SHAPE")) {              // experiments: force the run-time-shape kernel
         if (!strcmp(env, "any")) h->shape_default = h->shape_nobs50 = h->shape_n40 = false;
     }
-    h->map = make_map(*pb, h->P);
+    h->map = make_map(*pb, h->P == 40 ? 64 : h->P);      // (P = 40: the kernels compute their own map, nmpc_solve_hyb2.h)
     h->d_queue = nullptr;
     h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
     h->park_min = 500; h->park_depth = 8;
@@ -1120,7 +1121,8 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, device_id);
-    const size_t lds_bytes = (size_t)h->map.total * sizeof(double) * (64 / h->P);   // eval kernel: one slice per group
+    const size_t lds_bytes = h->P == 40 ? (size_t)nmpc::lds_layout2(pb->N, pb->nobs, pb->ndyn).total * sizeof(double) * 3
+                                        : (size_t)h->map.total * sizeof(double) * (64 / h->P);   // eval kernel: one slice per group
     if (lds_bytes > 160 * 1024) { nmpc_free(h); return NMPC_ERR_BAD_PROBLEM; }
     // the solve kernels use one LDS slice per wave; resident waves per CU are bounded by LDS and by
     // the register budget (2 waves per SIMD).  The hybrid kernel runs workgroups of four waves (teams).
@@ -1138,13 +1140,24 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
+    } else if (h->P == 40) {
+        // two stages per lane: one wave per SIMD (512 registers), the four waves of a CU are one team
+        const size_t wg_bytes = nmpc::TEAM_WAVES * (size_t)nmpc::lds_layout2(pb->N, pb->nobs, pb->ndyn).total * sizeof(double) +
+                                nmpc::TEAM_CTL_INTS * sizeof(int);
+        if (wg_bytes > 160 * 1024) { nmpc_free(h); return NMPC_ERR_BAD_PROBLEM; }
+        per_cu = nmpc::TEAM_WAVES;
+        h->team_lds = wg_bytes;
+        e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeN40>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_eval2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
     } else {
         per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
         if (per_cu > 8) per_cu = 8;
     }
     if (const char *env = getenv("NMPC_WAVES_PER_CU")) {       // tuning knob (experiments only)
         const int v = atoi(env);
-        if (v >= 1 && v <= per_cu && (h->P != 20 || v % nmpc::TEAM_WAVES == 0)) per_cu = v;
+        if (v >= 1 && v <= per_cu && ((h->P != 20 && h->P != 40) || v % nmpc::TEAM_WAVES == 0)) per_cu = v;
     }
     if (per_cu < 1) per_cu = 1;
     h->grid_cap = prop.multiProcessorCount * per_cu;
@@ -1172,7 +1185,8 @@ const char *nmpc_kernel_name(const nmpc_handle *h)
     if (h->P == 20)
         return h->shape_default ? "nmpc_solve_hyb_kernel<ShapeDefault>"
                                 : (h->shape_nobs50 ? "nmpc_solve_hyb_kernel<ShapeNobs50>" : "nmpc_solve_hyb_kernel<ShapeAny>");
-    return h->P == 32 ? "nmpc_solve_dual_kernel" : (h->shape_n40 ? "nmpc_solve_kernel<64, ShapeN40>" : "nmpc_solve_kernel<64>");
+    if (h->P == 40) return h->shape_n40 ? "nmpc_solve_hyb2_kernel<ShapeN40>" : "nmpc_solve_hyb2_kernel<ShapeAny>";
+    return h->P == 32 ? "nmpc_solve_dual_kernel" : "nmpc_solve_kernel<64>";
 }
 
 static void fill_args(const nmpc_handle *h, KArgs &a, int B)
@@ -1222,7 +1236,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
     const size_t lds = (size_t)h->map.total * sizeof(double);
 #endif
-    if (h->P == 20) {
+    if (h->P == 20 || h->P == 40) {
         // teams of four waves.  With fewer instances than workgroups fit on the chip every instance gets a workgroup of its
         // own (one wave solves, three help from the first iteration on: the small-batch / latency mode); otherwise as many
         // waves per workgroup take instances as it needs for all of them to start at once, up to all four.
@@ -1239,12 +1253,15 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
 #else
         const size_t tlds = h->team_lds;
 #endif
-        if (h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
+        if (h->P == 40) {
+            if (h->shape_n40) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeN40>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
+            else hipLaunchKernelGGL(nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeAny>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
+        }
+        else if (h->shape_default) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeDefault>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
         else if (h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
         else hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
     }
     else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
-    else if (h->shape_n40) hipLaunchKernelGGL((nmpc::nmpc_solve_kernel<64, nmpc::ShapeN40>), dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
@@ -1264,6 +1281,12 @@ int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const doubl
     fill_args(h, a, B);
     a.p = d_p; a.u = const_cast<double *>(d_u);
     a.ev_c = d_c; a.ev_y = d_y; a.ev_psi = d_psi; a.ev_grad = d_grad; a.ev_F1 = d_F1; a.ev_F2 = d_F2;
+    if (h->P == 40) {          // two stages per lane: three instances per wave
+        const size_t lds2 = (size_t)nmpc::lds_layout2(h->pb.N, h->pb.nobs, h->pb.ndyn).total * sizeof(double) * 3;
+        hipLaunchKernelGGL(nmpc::nmpc_eval2_kernel, dim3((B + 2) / 3), dim3(64), lds2, s, a);
+        HIP_TRY(h, hipGetLastError());
+        return NMPC_OK;
+    }
     const int K = 64 / h->P;
     const int grid = (B + K - 1) / K;
     const size_t lds = (size_t)h->map.total * sizeof(double) * K;

@@ -16,7 +16,10 @@
  *   multiply-add is meant; the file is compiled with -ffp-contract=off) and all reductions /
  *   scans over the horizon use a fixed, hardware-independent shape:
  *     tree_sum : zero-pad to P (32 for N <= 32, else 64); adjacent-pair binary tree
- *     prefix / suffix sums : Kogge-Stone inside blocks of 16 stages, then block carries
+ *     prefix / suffix sums : Kogge-Stone inside blocks of 16 stages, then block carries; for 32 < N <= 40 the
+ *                            PAIR form (two consecutive stages are summed first, the Kogge-Stone scan runs over the
+ *                            32 pair sums, the first stage of a pair adds its own value to the exclusive result):
+ *                            what a kernel that keeps two stages per lane computes (nmpc_solve_hyb2.h)
  *   so that an implementation on any machine with IEEE-754 f64 add/mul/fma/div/sqrt can
  *   reproduce the results bit for bit.  sin/cos are computed by orc_sincos() (Cody-Waite
  *   reduction + fdlibm kernels written with fma), never by libm.
@@ -145,6 +148,37 @@ static void ks_suffix(double *v, int P)
         for (int j = 0; j < 32; ++j) v[j] = v[j] + carry;
     }
 }
+
+/* PAIR form of the scans (horizons 32 < N <= 40, P = 64):  w_i = v[2i] + v[2i+1];  W = ks_prefix(w) over 32 entries;
+ *   prefix[2i+1] = W_i,  prefix[2i] = (i ? W_{i-1} : 0.0) + v[2i];
+ * suffix, the mirror image:  Z = ks_suffix(w);  suffix[2i] = Z_i,  suffix[2i+1] = (i < 31 ? Z_{i+1} : 0.0) + v[2i+1]. */
+static void pair_prefix(double *v)
+{
+    double w[32], out[64];
+    for (int i = 0; i < 32; ++i) w[i] = v[2 * i] + v[2 * i + 1];
+    ks_prefix(w, 32);
+    for (int i = 0; i < 32; ++i) {
+        out[2 * i + 1] = w[i];
+        out[2 * i] = (i ? w[i - 1] : 0.0) + v[2 * i];
+    }
+    memcpy(v, out, sizeof(out));
+}
+
+static void pair_suffix(double *v)
+{
+    double w[32], out[64];
+    for (int i = 0; i < 32; ++i) w[i] = v[2 * i] + v[2 * i + 1];
+    ks_suffix(w, 32);
+    for (int i = 0; i < 32; ++i) {
+        out[2 * i] = w[i];
+        out[2 * i + 1] = (i < 31 ? w[i + 1] : 0.0) + v[2 * i + 1];
+    }
+    memcpy(v, out, sizeof(out));
+}
+
+/* the scans of a horizon of N stages padded to P entries */
+static void scan_prefix(double *v, int P, int N) { if (N > 32 && N <= 40) pair_prefix(v); else ks_prefix(v, P); }
+static void scan_suffix(double *v, int P, int N) { if (N > 32 && N <= 40) pair_suffix(v); else ks_suffix(v, P); }
 
 /* max/min with the semantics of the IEEE maxNum/minNum the GPU's v_max_f64/v_min_f64 implement,
  * for the non-NaN operands this path produces (second operand is always a finite constant) */
@@ -283,13 +317,13 @@ static void eval_psi(const inst_t *I, const hvec *u, double c, const hvec *y, in
 
     /* rollout (:88-90) as three prefix sums */
     for (int j = 0; j < P; ++j) tmp[j] = u->w[j];
-    ks_prefix(tmp, P);
+    scan_prefix(tmp, P, N);
     for (int j = 0; j < P; ++j) thn[j] = fma(ts, tmp[j], I->th0);
     for (int j = 0; j < P; ++j) th[j] = j == 0 ? I->th0 : thn[j - 1];
     for (int j = 0; j < P; ++j) orc_sincos(th[j], &sn[j], &cs[j]);
     for (int j = 0; j < P; ++j) { tmp[j] = u->v[j] * cs[j]; tmp2[j] = u->v[j] * sn[j]; }
-    ks_prefix(tmp, P);
-    ks_prefix(tmp2, P);
+    scan_prefix(tmp, P, N);
+    scan_prefix(tmp2, P, N);
     for (int j = 0; j < P; ++j) { xn[j] = fma(ts, tmp[j], I->x0); yn[j] = fma(ts, tmp2[j], I->y0); }
     for (int j = 0; j < P; ++j) { xp[j] = j == 0 ? I->x0 : xn[j - 1]; yp[j] = j == 0 ? I->y0 : yn[j - 1]; }
 
@@ -415,15 +449,15 @@ static void eval_psi(const inst_t *I, const hvec *u, double c, const hvec *y, in
         qa[t] = fma(c, sv[t], (2.0 * I->pa) * o->av[t]);     /* d psi / d acc_t       */
         qw[t] = fma(c, sw[t], (2.0 * I->pw) * o->aw[t]);     /* d psi / d omega_acc_t */
     }
-    ks_suffix(Gx, P);
-    ks_suffix(Gy, P);
+    scan_suffix(Gx, P, N);
+    scan_suffix(Gy, P, N);
     double Dt[MAXP];
     for (int t = 0; t < P; ++t) {
         const double e = fma(Gy[t], cs[t], -(Gx[t] * sn[t]));
         Dt[t] = t < N ? (ts * u->v[t]) * e : 0.0;
     }
     for (int t = 0; t < P; ++t) tmp[t] = t < N ? Gt[t] + (t + 1 < P ? Dt[t + 1] : 0.0) : 0.0;
-    ks_suffix(tmp, P);
+    scan_suffix(tmp, P, N);
     for (int t = 0; t < P; ++t) {
         if (t >= N) { o->g.v[t] = o->g.w[t] = 0.0; continue; }
         const double qan = t + 1 < P ? qa[t + 1] : 0.0, qwn = t + 1 < P ? qw[t + 1] : 0.0;

@@ -108,12 +108,12 @@ def test_solve_nobs50_and_dynamic_obstacles(solvers):
 
 
 SHAPES = [(20, 10, 2), (20, 0, 0), (19, 10, 3), (17, 4, 1), (16, 0, 0), (15, 3, 2), (5, 1, 3), (2, 0, 0),
-          (21, 10, 3), (32, 64, 3), (33, 10, 3), (64, 3, 0)]
+          (21, 10, 3), (32, 64, 3), (33, 10, 3), (34, 0, 0), (37, 3, 1), (39, 12, 2), (40, 4, 3), (41, 10, 3), (64, 3, 0)]
 
 
 @pytest.mark.parametrize("N,nobs,ndyn", SHAPES)
 def test_shape_sweep_bit_exact(N, nobs, ndyn):
-    """Every lane layout (three / two / one query point per wave) with full and partial horizons,
+    """Every lane layout (three / two / one query point per wave; one and two stages per lane) with full and partial horizons,
     padded and empty obstacle tables: cost layer and solve against the oracle, bit for bit."""
     from mpc_trajectory_generator_amd.config import load_config
     from mpc_trajectory_generator_amd.solver import BatchSolver
@@ -141,8 +141,10 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
                                              ("cfg1", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
                                              ("cfg3", {}, "nmpc_solve_hyb_kernel<ShapeNobs50>"),
                                              ("cfg3", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
-                                             ("cfg2", {}, "nmpc_solve_kernel<64, ShapeN40>"),
-                                             ("cfg2", {"NMPC_SHAPE": "any"}, "nmpc_solve_kernel<64>")])
+                                             ("cfg2", {}, "nmpc_solve_hyb2_kernel<ShapeN40>"),
+                                             ("cfg2", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb2_kernel<ShapeAny>"),
+                                             ("cfg2", {"NMPC_TEAM_HELP": "0"}, "nmpc_solve_hyb2_kernel<ShapeN40>"),
+                                             ("cfg2", {"NMPC_TEAM_OWNERS": "4"}, "nmpc_solve_hyb2_kernel<ShapeN40>")])
 def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
     """Shapes with a specialised kernel: the run-time-shape kernel and the two-point kernel (used for
     20 < N_hor <= 32) must give the same bits on them; the handle reports which kernel runs."""
@@ -454,7 +456,7 @@ def test_per_instance_solve_time(solvers, name, B, monkeypatch):
 @pytest.mark.parametrize("env", [{"NMPC_TEAM_HELP": "0"}, {"NMPC_TEAM_OWNERS": "4"}, {"NMPC_TEAM_OWNERS": "2"},
                                  {"NMPC_TEAM_OWNERS": "1"}, {}],
                          ids=["no-help", "4-owners", "2-owners", "1-owner", "auto"])
-@pytest.mark.parametrize("name,B", [("cfg1", 160), ("cfg3", 40), ("cfg4", 40), ("n17", 24)])
+@pytest.mark.parametrize("name,B", [("cfg1", 160), ("cfg3", 40), ("cfg4", 40), ("n17", 24), ("cfg2", 24), ("n35", 12)])
 def test_team_modes_same_bits(monkeypatch, name, B, env):
     """The teams of the hybrid kernel (nmpc_solve_hyb.h): whether nobody helps, helpers appear only as the waves of a
     workgroup run out of work (4 owners), or every instance has helpers from its first iteration (1 owner, the
@@ -462,8 +464,9 @@ def test_team_modes_same_bits(monkeypatch, name, B, env):
     including the pass count of the three-point schedule."""
     from mpc_trajectory_generator_amd.config import load_config
     from mpc_trajectory_generator_amd.solver import BatchSolver
-    cfg = load_config(N_hor=17, Nobs=4, Ndynobs=1) if name == "n17" else named_config(name)
-    P = synthetic_batch(cfg, 11, B, 2718, synthetic_circles=(name == "cfg3"), random_dyn=(name in ("cfg4", "n17")))
+    cfg = {"n17": lambda: load_config(N_hor=17, Nobs=4, Ndynobs=1), "n35": lambda: load_config(N_hor=35, Nobs=6, Ndynobs=2)}.get(
+        name, lambda: named_config(name))()
+    P = synthetic_batch(cfg, 11, B, 2718, synthetic_circles=(name == "cfg3"), random_dyn=(name in ("cfg4", "n17", "n35")))
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     s = BatchSolver(cfg, max_batch=B)
