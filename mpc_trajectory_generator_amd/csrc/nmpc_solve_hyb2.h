@@ -232,7 +232,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int f = 0; f < 5; ++f) cur[j][f] = sg[j * SEG_STRIDE + f];
-#pragma unroll SH::N > 0 ? 4 : 1
+#pragma unroll SH::N > 0 ? 4 : 1      // (measured on MI355X, us per lone pass: unroll 2 8.43, 4 8.28, all twenty trips 19.6)
         for (int i = 0; i < nseg4; i += 2) {
             sg += 2 * SEG_STRIDE;                           // table is padded: reading one pair past the end is safe
 #pragma unroll

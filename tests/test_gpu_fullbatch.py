@@ -24,7 +24,7 @@ def bench_batch(name, seed=0):
 
 
 @pytest.mark.parametrize("name,kernel,sample", [("cfg1", "nmpc_solve_hyb_kernel<ShapeDefault>", 64),
-                                                ("cfg2", "nmpc_solve_kernel<64, ShapeN40>", 24),
+                                                ("cfg2", "nmpc_solve_hyb2_kernel<ShapeN40>", 24),
                                                 ("cfg3", "nmpc_solve_hyb_kernel<ShapeNobs50>", 48),
                                                 ("cfg4", "nmpc_solve_hyb_kernel<ShapeDefault>", 48)])
 def test_full_batch_properties_and_sampled_parity(name, kernel, sample):
