@@ -29,4 +29,7 @@ python bench.py --steps 5 --warmup 1 --budget 1500 --no-cpu-baseline > "$OUT/ben
 NMPC_BENCH_FORCE_DIST=1 python bench.py --steps 5 --warmup 1 --no-extras > "$OUT/bench_rccl_world1.json" 2> "$OUT/bench_rccl_world1.log"
 python scripts/bench_receding.py > "$OUT/bench_receding.json" 2> "$OUT/bench_receding.log"
 python scripts/perf_probe.py $TAG > "$OUT/perf_probe.json" 2> "$OUT/perf_probe.log"
+for c in cfg1 cfg3 cfg4; do python scripts/seeds_unseen.py $c > "$OUT/seeds_unseen_$c.json" 2> "$OUT/seeds_unseen_$c.log"; done
+for c in cfg1 cfg2; do python scripts/latency_team.py $c > "$OUT/latency_team_$c.json" 2> "$OUT/latency_team_$c.log"; done
+rocprofv3 --pmc $SQ1 -d "$OUT/pmc_cfg2_sq" -o pmc --output-format csv -- python scripts/pmc_cfg2.py > "$OUT/pmc_cfg2_sq.log" 2>&1
 python scripts/profile_summarise.py "$OUT"
