@@ -53,6 +53,10 @@ def test_bench_multi_gpu_path_over_rccl_world1():
     assert out["n_gpus"] == 1 and out["gather_checked"] is True
     assert "RCCL all_gather" in out["config"]["gather"]
     assert out["value"] > 0 and out["config"]["batch_per_gpu"] == 1024
+    # one line per rank (a wrong rank -> device mapping is visible) and the gather timed alone
+    assert [r_["rank"] for r_ in out["ranks"]] == [0] and out["ranks"][0]["shard"] == [0, 1024] and out["ranks"][0]["device"] == 0
+    assert out["ranks"][0]["kernel_ms"] > 0 and 0 < out["gather_alone"]["ms"] < out["ms_per_step"]
+    assert out["gather_alone"]["bytes_per_rank"] == 1024 * (40 + 40 + 9) * 8
     # the same batch without the collective: same solver work (the gather changes nothing but the time)
     r2 = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "1024", "--no-extras"])
     assert r2.returncode == 0, r2.stderr[-2000:]
