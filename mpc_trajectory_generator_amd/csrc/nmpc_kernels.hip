@@ -84,6 +84,7 @@ struct KArgs {
     int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
     int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
     int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
+    double cull_radius;        // eval_psi's CULL path: circles whose edge is farther than this from the start position are left out of the scan
     // eval kernel only
     const double *ev_c;
     const double *ev_y;
@@ -183,7 +184,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     NMPC_WAVE_SYNC();
     vref = t < N ? p[NZ + t] : 0.0;
     const double *ps = p + NZ + N;
-    for (int k = t; k < ((nobs + 3) & ~3); k += P) {       // padded to a multiple of 4 with inert zero circles
+    for (int k = t; k < ((nobs + 4) & ~3); k += P) {       // padded to a multiple of 4 with inert zero circles (slot `nobs` always is one)
         const bool real = k < nobs;
         const double r = real ? ps[3 * k + 2] : 0.0;
         L[mp.obs + 3 * k] = real ? ps[3 * k] : 0.0;
@@ -235,6 +236,18 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     NMPC_WAVE_SYNC();
 }
 
+// the circles of an instance whose edge lies within `radius` of the start position (bit k = circle k); padding slots (r = 0) never are
+__device__ __forceinline__ unsigned long long circle_near_mask(const double *p, int N, int nobs, int lane, double radius)
+{
+    const double *ps = p + NZ + N;
+    bool keep = false;
+    if (lane < nobs) {
+        const double dx = ps[3 * lane] - p[0], dy = ps[3 * lane + 1] - p[1], r = ps[3 * lane + 2], lim = radius + r;
+        keep = r > 0.0 && fma(dx, dx, dy * dy) <= lim * lim;
+    }
+    return __ballot(keep);
+}
+
 // ---------------------------------------------------------------------------------------------
 // psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); WRITE_F2: F2_k also left in the LDS slice
 // ---------------------------------------------------------------------------------------------
@@ -246,11 +259,14 @@ __device__ long long nmpc_dummy_;
 #else
 #define NMPC_EVTICK(i) do { } while (0)
 #endif
-template <int P, class SH = ShapeAny, bool WRITE_F2 = false>
+// CULL: `near` is the set of static circles that can be touched at all while every stage stays within KArgs.cull_radius of the start
+// position (circle_near_mask below); the activity scan visits those only, and falls back to all of them for an evaluation in
+// which some stage is farther away -- so the result is exactly that of the full scan.
+template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
-                                         double &gw, double &av_out, double &aw_out)
+                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
@@ -369,6 +385,37 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     {
         const lds_double *ob = L + mp.obs;
         const int nobs4 = (nobs + 3) & ~3;
+        if constexpr (CULL) {
+            // only the circles of `near` -- unless a stage of this evaluation has left the radius the set was made for
+            const unsigned long long all = nobs >= 64 ? ~0ull : (1ull << nobs) - 1ull;
+            unsigned long long todo = near & all;
+            if (todo != all) {
+                const double rx = xn - x0, ry = yn - y0;
+                const double rg = 0.999 * a.cull_radius;
+                if (__any(in_r && !(fma(rx, rx, ry * ry) <= rg * rg))) todo = all;
+            }
+            while (todo) {                                  // four circles per trip; slot `nobs` holds an inert zero circle
+                int kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kk[j] = todo ? __builtin_ctzll(todo) : nobs;
+                    todo &= todo - (todo ? 1ull : 0ull);
+                }
+                double od[12];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const lds_double *oj = ob + 3 * kk[j];
+                    od[3 * j] = oj[0]; od[3 * j + 1] = oj[1]; od[3 * j + 2] = oj[2];
+                }
+                NMPC_SCHED_BARRIER();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
+                    const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
+                    if (__any(in_r && h > 0.0)) act |= 1ull << (kk[j] & 63);          // (the inert circle never is)
+                }
+            }
+        } else {
 #pragma unroll SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1
         for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, one ballot each
             double od[12];
@@ -381,6 +428,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                 const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
                 if (__any(in_r && h > 0.0)) act |= 1ull << (k + j);
             }
+        }
         }
         NMPC_EVTICK(5);     // static circle scan
         {
@@ -1016,6 +1064,7 @@ struct nmpc_handle {
     int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
     int team_owners_forced;    // experiments (NMPC_TEAM_OWNERS): waves per workgroup that take instances, 0 = automatic
     int team_help;             // experiments (NMPC_TEAM_HELP=0): helpers never asked
+    double cull_radius;        // eval_psi CULL (NMPC_CULL_RADIUS)
     double *d_park;            // parked solver states, allocated on first use
     int *d_pool;
     unsigned int *d_pool_ctr;
@@ -1108,6 +1157,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
     h->team_owners_forced = 0;
     h->team_help = 1;
+    // culling radius: what the input bounds let the robot travel in a horizon, plus a margin (any value is exact: an evaluation
+    // with a stage beyond it scans every circle); NMPC_CULL_RADIUS overrides it (tests use 0.5 m: the fall-back runs all the time)
+    h->cull_radius = 1.1 * pb->N * pb->ts * fmax(fabs(pb->vmin), fabs(pb->vmax));
+    if (const char *env = getenv("NMPC_CULL_RADIUS")) { const double v = atof(env); if (v > 0.0) h->cull_radius = v; }
     if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
     if (const char *env = getenv("NMPC_TEAM_OWNERS")) { const int v = atoi(env); if (v >= 1 && v <= nmpc::TEAM_WAVES) h->team_owners_forced = v; }
     h->d_order = nullptr;
@@ -1248,6 +1301,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         if (wgs > max_wgs) wgs = max_wgs;
         a.team_owners = owners;
         a.team_help = h->team_help;
+        a.cull_radius = h->cull_radius;
 #ifdef NMPC_PROFILE
         const size_t tlds = lds;
 #else

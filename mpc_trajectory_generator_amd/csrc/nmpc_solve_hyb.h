@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // with a 20-stage horizon every stage lane of the evaluation layout is inside it (lanes 60..63 may
     // hold don't-care values: no cross-lane operation lets them into other lanes)
     constexpr bool FULL = SH::N == PE;
+    constexpr bool CULL = SH::NOBS > 16 || SH::NOBS < 0;      // many circle slots: scan only those the robot can reach (eval_psi)
     const bool inea = FULL ? true : ine;
     const LdsMap mp = the_map<SH, PE>(a);
     const int n2 = shape_nobs<SH>(a) + shape_ndyn<SH>(a);
@@ -201,6 +202,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         DynStage dyn;
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
+        unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
+        if constexpr (CULL) {
+            near = circle_near_mask(a.p + (size_t)inst * a.n_p, N, shape_nobs<SH>(a), lane, a.cull_radius);
+            if (lane == 0) { Lpar[18] = __hiloint2double((int)(near >> 32), (int)near); }
+        }
 
         // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
         // a fresh instance starts from the caller's u0 / y0; a resumed one from its parked state (acquired by pool_pop)
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zXv = lane_get(xv, zsrcX), zXw = lane_get(xw, zsrcX);
             const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
-            eval_psi<PE, SH>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+            eval_psi<PE, SH, false, CULL>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
@@ -816,7 +822,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         const double tau_w = __hiloint2double((1023 - (2 + 3 * k + q)) << 20, 0), omt_w = 1.0 - tau_w;
         const double zv = fma(-tau_w, d_.x, fma(-omt_w, r_.x, u_.x)), zw = fma(-tau_w, d_.y, fma(-omt_w, r_.y, u_.y));
         double psi, pen, egv = 0, egw = 0, eav, eaw;
-        eval_psi<PE, SH>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw);
+        unsigned long long near_w = ~0ull;
+        if constexpr (CULL) { const double nb_ = Lw[mp.par + 18]; near_w = ((unsigned long long)(unsigned)__double2hiint(nb_) << 32) | (unsigned)__double2loint(nb_); }
+        eval_psi<PE, SH, false, CULL>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w);
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute
         const double gam_w = Lw[mp.par + 17];
