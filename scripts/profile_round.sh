@@ -18,10 +18,11 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:$SQ1" "wait:$SQ2"; do
     name=${pass%%:*}; ctrs=${pass#*:}
     rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_one.py > "$OUT/pmc_$name.log" 2>&1
 done
-for pass in "lone_sq:$SQ1" "lone_wait:$SQ2"; do
+for pass in "lone_sq:$SQ1" "lone_wait:$SQ2"; do      # ONE wave on the chip: helpers off
     name=${pass%%:*}; ctrs=${pass#*:}
-    rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_$name.log" 2>&1
+    NMPC_TEAM_HELP=0 rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_$name.log" 2>&1
 done
+rocprofv3 --pmc $SQ1 -d "$OUT/pmc_team_sq" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_team_sq.log" 2>&1      # the same instance with its three helpers
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.log"
 for c in cfg2 cfg3 cfg4; do python bench.py --config $c --steps 3 --warmup 1 --no-pipelined > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.log"; done
 python bench.py --config cfg3 --batch 65536 --steps 2 --warmup 1 --no-extras > "$OUT/bench_cfg3_64k.json" 2> "$OUT/bench_cfg3_64k.log"

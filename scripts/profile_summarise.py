@@ -15,7 +15,7 @@ if cands:
     with open(os.path.join(out, "kernel_stats.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(rows)
 per_kernel = {}
-for name in ("fetch", "write", "sq", "wait", "lone_sq", "lone_wait", "cfg2_sq"):
+for name in ("fetch", "write", "sq", "wait", "lone_sq", "lone_wait", "team_sq", "cfg2_sq"):
     files = glob.glob(os.path.join(out, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)
     if not files:
         continue
