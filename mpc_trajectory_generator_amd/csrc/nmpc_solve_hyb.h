@@ -790,7 +790,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     for (;;) {
-        if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;
+        if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         // claim the next open task of some sibling's request
         int got = -1;
         if (lane == 0) {

@@ -585,6 +585,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
         bool posted = false;
+#ifdef NMPC2_TICKS      // scripts/hyb2_sections.py: s_memtime ticks per section of a pass (fenced: upper bounds), reported in the status reals
+        long long tk[5] = {0, 0, 0, 0, 0}, tkl = __builtin_amdgcn_s_memtime();
+#define NMPC2_TK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); tk[((i) + 4) % 5] += t_ - tkl; tkl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NMPC2_TK(i) do { } while (0)
+#endif
 
         for (;;) {
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
@@ -786,6 +792,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             double psi, pen;
             D2 egv = d2s(0.0), egw = d2s(0.0), eav, eaw;
             n_pass++;
+            NMPC2_TK(0);
             // query points: state layout -> LDS -> evaluation layout (X of half 0 | X of half 1 | Y)
             if (t < H2_ENT) {
                 st4(Pts + 2 * (h * H2_ENT + t), xv, xw);
@@ -795,10 +802,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             D2 zv, zw, yv, yw;
             ld4(Pts + 2 * (q * H2_ENT + te), zv, zw);
             ld4(Ly, yv, yw);
+            NMPC2_TK(1);
             eval_psi2<SH>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw);
+            NMPC2_TK(2);
             if (need_grad) st4(Grd + 2 * (q * H2_ENT + te), egv, egw);
             NMPC_WAVE_SYNC();
             const double psiA = point_scalar(psi, 0), psiB = point_scalar(psi, 1), psiC = point_scalar(psi, 2);
+            NMPC2_TK(3);
 #define NMPC2_TAKE_TRIAL(PSI, K) NMPC2_TAKE_TRIAL_(PSI, NMPC2_LOAD_GRAD(Grd + 2 * (K) * H2_ENT, gv, gw))
 #define NMPC2_TAKE_TRIAL_(PSI, FETCH)                                                  \
             do {                                                                       \
@@ -1001,6 +1011,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             s.penalty = pen_c;
             s.cost = last_cost;
             s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - t_start) * 1e-5;
+#ifdef NMPC2_TICKS
+            s.last_problem_norm_fpr = (double)tk[4]; s.delta_y_norm_over_c = (double)tk[0]; s.f2_norm = (double)tk[1]; s.penalty = (double)tk[2]; s.cost = (double)tk[3];
+#endif
             a.st[inst] = s;
         }
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
@@ -1012,7 +1025,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     for (;;) {
-        if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;
+        if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         int got = -1;
         if (lane == 0) {
             for (int w = 0; w < TEAM_WAVES && got < 0; ++w) {
@@ -1058,6 +1071,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
     }
 }
 
+#undef NMPC2_TK
 #undef NMPC2_HALF_STEP
 #undef NMPC2_FBE
 #undef NMPC2_LOAD_GRAD
