@@ -29,11 +29,13 @@ def _fleet(cfg, route, B, seed, K):
 
 
 @pytest.mark.parametrize("name,scene,K,steps,sinus", [("cfg4", 11, 3, 12, False), ("cfg4", 1, 2, 40, False), ("cfg1", 11, 0, 8, False),
-                                                       ("nobs3", 11, 1, 6, False), ("cfg4", 11, 3, 10, True)])
+                                                       ("nobs3", 11, 1, 6, False), ("cfg4", 11, 3, 10, True),
+                                                       ("cfg2", 11, 2, 5, False)])
 def test_device_loop_equals_host_mirror(name, scene, K, steps, sinus):
     from mpc_trajectory_generator_amd.solver import BatchSolver
     from mpc_trajectory_generator_amd.trajectory import DeviceRecedingHorizon, VectorizedRecedingHorizon
-    # "nobs3": fewer circle slots than the scene has vertices -> the closest-vertex window is exercised
+    # "nobs3": fewer circle slots than the scene has vertices -> the closest-vertex window is exercised; "cfg2": N_hor = 40, the
+    # two-stages-per-lane kernel inside the loop
     cfg = load_config(Nobs=3) if name == "nobs3" else named_config(name)
     route = harness.scene_route(cfg, scene)
     B = 24
