@@ -520,3 +520,14 @@ def test_circle_culling_is_exact(monkeypatch, name, B, radius):
     cpu = oracle_for(cfg).solve_batch(P, threads=8)
     assert_same_solution(gpu, cpu)
     assert (cpu[2]["penalty"] > 1.0).any() and (cpu[2]["num_outer_iterations"] > 2).any()      # the circles did matter
+
+
+def test_results_do_not_depend_on_timing():
+    """Helpers, migration and the work queue decide WHERE and WHEN work runs, never what comes out: repeated solves of the same
+    batches -- sizes that put every instance in a team from the start, that mix owners and helpers, and that exceed the resident
+    waves -- give identical bits every time (scripts/stress_teams.py is the long version)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stress_teams.py"), "6"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=900)
+    assert r.returncode == 0 and "STRESS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
