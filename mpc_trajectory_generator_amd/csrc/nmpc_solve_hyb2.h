@@ -690,7 +690,31 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     }
                     // ---- d = H r, two-loop recursion over the tentative buffer (each trip fetches the NEXT pair first) ----
                     dv = rv; dw = rw;
-                    if (n_active > 0) {
+                    if (n_active == MAXMEM && m == MAXMEM) {
+                        // full buffer (the steady state): branch-free, all pairs addressed from the head, no register rotation
+                        double alpha[MAXMEM];
+#pragma unroll
+                        for (int k = 0; k < MAXMEM; ++k) {
+                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
+                            D2 s1_, s2_, y1_, y2_;
+                            ld4(LS + 2 * (slot * H2_NS + tt), s1_, s2_);
+                            ld4(LY + 2 * (slot * H2_NS + tt), y1_, y2_);
+                            const double al = Lrho[slot] * group_sum<P>(hdot2(s1_, s2_, dv, dw), lane);
+                            alpha[k] = al;
+                            dv = fma2(-al, y1_, dv); dw = fma2(-al, y2_, dw);
+                        }
+                        dv = n_H0 * dv; dw = n_H0 * dw;
+#pragma unroll
+                        for (int k = MAXMEM - 1; k >= 0; --k) {
+                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
+                            D2 s1_, s2_, y1_, y2_;
+                            ld4(LS + 2 * (slot * H2_NS + tt), s1_, s2_);
+                            ld4(LY + 2 * (slot * H2_NS + tt), y1_, y2_);
+                            const double be = Lrho[slot] * group_sum<P>(hdot2(y1_, y2_, dv, dw), lane);
+                            const double ab = alpha[k] - be;
+                            dv = fma2(ab, s1_, dv); dw = fma2(ab, s2_, dw);
+                        }
+                    } else if (n_active > 0) {
                         double alpha[MAXMEM];
                         int slot = n_head;
                         D2 sc1, sc2, yc1, yc2;
