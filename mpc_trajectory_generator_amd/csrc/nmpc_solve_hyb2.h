@@ -221,6 +221,9 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
         acc = fma2(sc[SC_Q], fma2(ddx, ddx, ddy * ddy), acc);
         acc = fma2(sc[SC_QTH] * dth, dth, acc);
     }
+    // (the shifts of the accelerations are issued here: their LDS round trips then run under the cross-track loop)
+    const D2 vprev = prev2(zv, lane, sc[SC_VINIT]);
+    const D2 wprev = prev2(zw, lane, sc[SC_WINIT]);
     // cross-track error: min over the N-1 reference segments (:121-144); a segment is read once for both stages
     D2 best = d2s(__builtin_inf());
     int bia = 0, bib = 0;
@@ -265,8 +268,6 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
     }
     acc = fma2(sc[SC_QCTE], best, acc);                                           // (:144)
     // accelerations (:160-161), their cost (:170-171) and the ALM term
-    const D2 vprev = prev2(zv, lane, sc[SC_VINIT]);
-    const D2 wprev = prev2(zw, lane, sc[SC_WINIT]);
     D2 av = inv_ts * (zv - vprev), aw = inv_ts * (zw - wprev);
     acc = fma2(sc[SC_PA] * av, av, acc);
     acc = fma2(sc[SC_PW] * aw, aw, acc);
