@@ -53,6 +53,7 @@ struct LdsMap {
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x dyn_stride per-stage ellipse data
     int dyn_stride;  // columns per (ellipse, field): 24 / 32 for the three- / two-point layouts, N rounded up to even for one point
+    int win;     // hybrid kernel, windowed cross-track search: per window start, the squared distance from the window's anchor to the nearest segment outside it
     int req;     // hybrid kernel, team mode: the line-search request of this wave's instance -- u, r, d as 3 x 24 (v, w) pairs by stage
     int vec;     // 7 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed, grad at u_k
     int rho;     // m
@@ -153,6 +154,7 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     mp.dyn_stride = P == 64 ? ((N + 1) & ~1) : (P == 20 ? 24 : P);
     mp.dyn = o; o += NDYN_MAX * 6 * mp.dyn_stride;
     o = (o + 1) & ~1;
+    mp.win = o; o += P == 20 ? 2 * 24 : 0;           // per centre segment: anchor x | anchor y (its squared clearance rides in the segment's spare slot)
     mp.req = o; o += P == 20 ? TEAM_REQ_DOUBLES : 0;
     mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
     o = (o + 1) & ~1;                                 // 16-byte alignment for the double2 arrays
@@ -236,6 +238,35 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     NMPC_WAVE_SYNC();
 }
 
+// windowed cross-track search (eval_psi, WIN): for every segment c -- the previous arg-min of a lane -- the anchor A_c = its midpoint and the
+// squared distance from A_c to the nearest segment OUTSIDE the window around c (the window is clamped to the table at its ends; infinity if
+// nothing is outside); same distance formula as the search
+template <int WIN>
+__device__ __forceinline__ void window_table(lds_double *L, const LdsMap &mp, int N, int lane)
+{
+    const int nseg = N - 1;
+    if (nseg >= 2 * WIN + 1 && lane < nseg) {
+        int i0 = lane - WIN;
+        i0 = i0 < 0 ? 0 : (i0 > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0);
+        const lds_double *sc_ = L + mp.seg + SEG_STRIDE * lane;
+        const double Ax = fma(0.5, sc_[2], sc_[0]), Ay = fma(0.5, sc_[3], sc_[1]);
+        double dmin = __builtin_inf();
+        for (int i = 0; i < nseg; ++i) {
+            const lds_double *sg = L + mp.seg + SEG_STRIDE * i;
+            const double px = Ax - sg[0], py = Ay - sg[1];
+            const double dot = fma(px, sg[2], py * sg[3]);
+            const double tst = fmin(fmax(dot * sg[4], 0.0), 1.0);
+            const double ex = fma(tst, sg[2], -px), ey = fma(tst, sg[3], -py);
+            const double d2 = fma(ex, ex, ey * ey);
+            dmin = (i < i0 || i > i0 + 2 * WIN) ? fmin(dmin, d2) : dmin;
+        }
+        L[mp.win + lane] = Ax;
+        L[mp.win + 24 + lane] = Ay;
+        L[mp.seg + SEG_STRIDE * lane + 5] = dmin;        // (the segment entries' spare sixth slot)
+    }
+    NMPC_WAVE_SYNC();
+}
+
 // the circles of an instance whose edge lies within `radius` of the start position (bit k = circle k); padding slots (r = 0) never are
 __device__ __forceinline__ unsigned long long circle_near_mask(const double *p, int N, int nobs, int lane, double radius)
 {
@@ -262,11 +293,11 @@ __device__ long long nmpc_dummy_;
 // CULL: `near` is the set of static circles that can be touched at all while every stage stays within KArgs.cull_radius of the start
 // position (circle_near_mask below); the activity scan visits those only, and falls back to all of them for an evaluation in
 // which some stage is farther away -- so the result is exactly that of the full scan.
-template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false>
+template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, int WIN = 0>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
-                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull)
+                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, int *ctr = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
@@ -310,7 +341,48 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     // cross-track error: min over the N-1 reference segments (:121-144)
     double best = __builtin_inf();
     int bi = 0;
-    {
+    bool full_scan = true;
+    if constexpr (WIN > 0) {
+        // WINDOWED SEARCH (exact).  From one evaluation to the next a stage's nearest segment moves by a segment or two, so only the
+        // 2 WIN + 1 segments around the previous arg-min are measured -- per-lane LDS gathers instead of broadcasts -- and the result
+        // is accepted if it is PROVABLY the global one: with A the midpoint of the previous arg-min segment and D the distance from A
+        // to the nearest segment outside the window (table `win`, made at instance set-up), every outside segment is at least
+        // D - |p - A| away from p, so  |p - A| + d_window < D  rules them all out; tested without square roots as
+        // 2 (|p - A|^2 + d_window^2) < D^2, with 0.4 % margin for rounding.  If any stage
+        // of the wave fails the test the full scan below runs instead; either way `best`, `bi` are those of the full scan.
+        const int nseg = N - 1;
+        if (nseg >= 2 * WIN + 1) {
+            int cc = *ctr;
+            cc = cc < 0 ? 0 : (cc > nseg - 1 ? nseg - 1 : cc);
+            int i0 = cc - WIN;
+            i0 = i0 < 0 ? 0 : (i0 > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0);
+            const lds_double *sg = L + mp.seg + SEG_STRIDE * i0;
+            double wv[2 * WIN + 1][5];
+#pragma unroll
+            for (int j = 0; j <= 2 * WIN; ++j)
+#pragma unroll
+                for (int f = 0; f < 5; ++f) wv[j][f] = sg[j * SEG_STRIDE + f];
+            const lds_double *wt = L + mp.win + cc;
+            const double Ax = wt[0], Ay = wt[24], dlim = L[mp.seg + SEG_STRIDE * cc + 5];
+#pragma unroll
+            for (int j = 0; j <= 2 * WIN; ++j) {
+                const double px = xn - wv[j][0], py = yn - wv[j][1];
+                const double dot = fma(px, wv[j][2], py * wv[j][3]);
+                const double that = dot * wv[j][4];
+                const double tst = fmin(fmax(that, 0.0), 1.0);
+                const double ex = fma(tst, wv[j][2], -px), ey = fma(tst, wv[j][3], -py);
+                const double d2 = fma(ex, ex, ey * ey);
+                bi = d2 < best ? i0 + j : bi;
+                best = fmin(best, d2);
+            }
+            const double ax = xn - Ax, ay = yn - Ay;
+            const double a2 = fma(ax, ax, ay * ay);
+            const bool sure = 2.008 * (a2 + best) < dlim;       // (|p - A| + d)^2 <= 2 (|p - A|^2 + d^2) < D^2
+            full_scan = __any(in_r && !sure);
+            if (full_scan) { best = __builtin_inf(); bi = 0; }
+        }
+    }
+    if (full_scan) {
         const lds_double *sg = L + mp.seg;
         const int nseg4 = (N - 1 + 3) & ~3;
         // software pipeline: the ten LDS reads of the NEXT pair of segments are issued before the current
@@ -350,6 +422,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                 for (int f = 0; f < 5; ++f) cur[j][f] = nxt[j][f];
         }
     }
+    if constexpr (WIN > 0) *ctr = bi;
     NMPC_EVTICK(1);     // stage cost + CTE loop
     acc = fma(sc[SC_QCTE], best, acc);                                            // (:144)
     // accelerations (:160-161), their cost (:170-171) and the ALM term

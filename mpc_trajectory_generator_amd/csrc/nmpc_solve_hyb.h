@@ -38,6 +38,10 @@
 // helper) written by that helper only, so a late writer of a stale request can never overwrite a current flag.
 #pragma once
 
+#ifndef NMPC_WIN
+#define NMPC_WIN 1
+#endif
+
 namespace nmpc {
 
 typedef __attribute__((address_space(3))) int lds_int;
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // hold don't-care values: no cross-lane operation lets them into other lanes)
     constexpr bool FULL = SH::N == PE;
     constexpr bool CULL = SH::NOBS > 16 || SH::NOBS < 0;      // many circle slots: scan only those the robot can reach (eval_psi)
+    constexpr int WIN = NMPC_WIN;                             // windowed cross-track search: half width in segments (eval_psi)
     const bool inea = FULL ? true : ine;
     const LdsMap mp = the_map<SH, PE>(a);
     const int n2 = shape_nobs<SH>(a) + shape_ndyn<SH>(a);
@@ -202,6 +207,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         DynStage dyn;
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
+        if constexpr (WIN > 0) window_table<WIN>(L, mp, N, lane);
+        int ctr = te < N - 1 ? te : N - 2;          // centre of this lane's cross-track window: the last arg-min
         unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
         if constexpr (CULL) {
             near = circle_near_mask(a.p + (size_t)inst * a.n_p, N, shape_nobs<SH>(a), lane, a.cull_radius);
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zXv = lane_get(xv, zsrcX), zXw = lane_get(xw, zsrcX);
             const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
-            eval_psi<PE, SH, false, CULL>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ctr);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
@@ -789,6 +796,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
         ctl_add(ctl + CTL_HELPERS, 1);
     }
+    int ctr_h = te < N - 1 ? te : N - 2;          // this helper lane's window centre (a stale one only costs a full scan)
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         // claim the next open task of some sibling's request
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         unsigned long long near_w = ~0ull;
         if constexpr (CULL) { const double nb_ = Lw[mp.par + 18]; near_w = ((unsigned long long)(unsigned)__double2hiint(nb_) << 32) | (unsigned)__double2loint(nb_); }
-        eval_psi<PE, SH, false, CULL>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w);
+        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ctr_h);
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute
         const double gam_w = Lw[mp.par + 17];
