@@ -241,6 +241,20 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
 // windowed cross-track search (eval_psi, WIN): for every segment c -- the previous arg-min of a lane -- the anchor A_c = its midpoint and the
 // squared distance from A_c to the nearest segment OUTSIDE the window around c (the window is clamped to the table at its ends; infinity if
 // nothing is outside); same distance formula as the search
+#ifdef NMPC_WIN_STATS
+__device__ unsigned long long nmpc_win_stats[2];       // windowed searches | of which fell back to the full scan
+#endif
+// is the windowed minimum `best` (squared) the global one?  a2 = |p - A|^2, dlim = D^2
+__device__ __forceinline__ bool window_is_global(double a2, double best, double dlim)
+{
+#ifdef NMPC_WIN_GUARD_LOOSE
+    return 2.008 * (a2 + best) < dlim;                   // (|p - A| + d)^2 <= 2 (|p - A|^2 + d^2) < D^2
+#else
+    // |p - A| + d < D  <=>  D^2 - |p - A|^2 - d^2 > 2 |p - A| d, squared once more; margins for rounding on both tests
+    const double t = dlim - (a2 + best);
+    return t > 0.004 * dlim && t * t > 4.016 * (a2 * best);
+#endif
+}
 template <int WIN>
 __device__ __forceinline__ void window_table(lds_double *L, const LdsMap &mp, int N, int lane)
 {
@@ -262,7 +276,7 @@ __device__ __forceinline__ void window_table(lds_double *L, const LdsMap &mp, in
         }
         L[mp.win + lane] = Ax;
         L[mp.win + 24 + lane] = Ay;
-        L[mp.seg + SEG_STRIDE * lane + 5] = dmin;        // (the segment entries' spare sixth slot)
+        L[mp.seg + SEG_STRIDE * lane + 5] = dmin > 1e-8 ? dmin : 0.0;   // (the segment entries' spare sixth slot; a reference that folds back on itself gets no window)
     }
     NMPC_WAVE_SYNC();
 }
@@ -377,8 +391,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             }
             const double ax = xn - Ax, ay = yn - Ay;
             const double a2 = fma(ax, ax, ay * ay);
-            const bool sure = 2.008 * (a2 + best) < dlim;       // (|p - A| + d)^2 <= 2 (|p - A|^2 + d^2) < D^2
+            const bool sure = window_is_global(a2, best, dlim);
             full_scan = __any(in_r && !sure);
+#ifdef NMPC_WIN_STATS
+            if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
+#endif
             if (full_scan) { best = __builtin_inf(); bi = 0; }
         }
     }
@@ -1718,5 +1735,15 @@ int nmpc_test_divsqrt_host(nmpc_handle *h, int n, const double *a, const double 
     if (!b) return NMPC_ERR_BAD_ARG;
     return run_unary_test(h, n, a, b, out_div, out_sqrt, 1);
 }
+
+#ifdef NMPC_WIN_STATS
+// experiments only (scripts/win_stats.py): windowed cross-track searches and how many of them fell back to the full scan
+int nmpc_debug_win_stats(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nmpc::nmpc_win_stats), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { const unsigned long long z[2] = {0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(nmpc::nmpc_win_stats), z, sizeof z); }
+    return e == hipSuccess ? NMPC_OK : NMPC_ERR_HIP;
+}
+#endif
 
 }  // extern "C"

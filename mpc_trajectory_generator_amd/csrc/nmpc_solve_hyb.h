@@ -38,6 +38,9 @@
 // helper) written by that helper only, so a late writer of a stale request can never overwrite a current flag.
 #pragma once
 
+#ifndef NMPC_CULL_MIN
+#define NMPC_CULL_MIN 16
+#endif
 #ifndef NMPC_WIN
 #define NMPC_WIN 1
 #endif
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // with a 20-stage horizon every stage lane of the evaluation layout is inside it (lanes 60..63 may
     // hold don't-care values: no cross-lane operation lets them into other lanes)
     constexpr bool FULL = SH::N == PE;
-    constexpr bool CULL = SH::NOBS > 16 || SH::NOBS < 0;      // many circle slots: scan only those the robot can reach (eval_psi)
+    constexpr bool CULL = SH::NOBS > NMPC_CULL_MIN || SH::NOBS < 0;      // many circle slots: scan only those the robot can reach (eval_psi)
     constexpr int WIN = NMPC_WIN;                             // windowed cross-track search: half width in segments (eval_psi)
     const bool inea = FULL ? true : ine;
     const LdsMap mp = the_map<SH, PE>(a);

@@ -82,6 +82,9 @@ struct LdsMap2 {
     int S, Y;     // L-BFGS ring: MAXMEM slots x 21 entries (20 lane pairs + a zero column) of 4 doubles
     int total;
 };
+#ifndef NMPC_WIN2
+#define NMPC_WIN2 2               // half width of the cross-track window of the two-stage kernel (measured: 1 -> 180.0, 2 -> 176.9 ms on config 2)
+#endif
 constexpr int H2_COLS = 32, H2_NS = 21, H2_ENT = 24;
 constexpr int TEAM2_AREA_DOUBLES = 3 * H2_ENT * 4 + 8;
 __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
@@ -197,7 +200,7 @@ __device__ __forceinline__ void window_table2(lds_double *L, const LdsMap2 &mp, 
         }
         L[mp.win + lane] = Ax;
         L[mp.win + 40 + lane] = Ay;
-        L[mp.seg + SEG_STRIDE * lane + 5] = dmin;
+        L[mp.seg + SEG_STRIDE * lane + 5] = dmin > 1e-8 ? dmin : 0.0;
     }
     NMPC_WAVE_SYNC();
 }
@@ -287,7 +290,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
                     bst = fmin(bst, d2);                                                                   \
                 }                                                                                          \
                 const double ax = xn.S_ - Ax, ay = yn.S_ - Ay;                                             \
-                sure = sure && 2.008 * (fma(ax, ax, ay * ay) + bst) < dlim;                                \
+                sure = sure && window_is_global(fma(ax, ax, ay * ay), bst, dlim);                          \
                 best.S_ = bst; BI_ = bi_;                                                                  \
             } while (0)
             NMPC2_WINDOW(a, bia, ctr[0]);
@@ -296,6 +299,9 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
             NMPC2_WINDOW(b, bib, ctr[1]);
 #undef NMPC2_WINDOW
             full_scan = __any((ra && !sure_a) || (rb && !sure));
+#ifdef NMPC_WIN_STATS
+            if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
+#endif
             if (full_scan) { best = d2s(__builtin_inf()); bia = bib = 0; }
         }
     }
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         if (inst < 0) break;
         const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
-        window_table2<NMPC_WIN>(L, mp, N, lane);
+        window_table2<NMPC_WIN2>(L, mp, N, lane);
         int ctr[2] = {2 * te < N - 1 ? 2 * te : N - 2, 2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2};      // centres of this lane's cross-track windows
 
         const double *u0 = a.u + (size_t)inst * a.n_u;
@@ -903,7 +909,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             ld4(Pts + 2 * (q * H2_ENT + te), zv, zw);
             ld4(Ly, yv, yw);
             NMPC2_TK(1);
-            eval_psi2<SH, false, NMPC_WIN>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ctr);
+            eval_psi2<SH, false, NMPC_WIN2>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ctr);
             NMPC2_TK(2);
             if (need_grad) st4(Grd + 2 * (q * H2_ENT + te), egv, egw);
             NMPC_WAVE_SYNC();
@@ -1155,7 +1161,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         const D2 zv = fma2(-tau_w, e1, fma2(-omt_w, r1, u1)), zw = fma2(-tau_w, e2, fma2(-omt_w, r2, u2));
         double psi, pen;
         D2 egv = d2s(0.0), egw = d2s(0.0), eav, eaw;
-        eval_psi2<SH, false, NMPC_WIN>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ctr_h);
+        eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ctr_h);
         // the trial's forward-backward envelope, in the evaluation layout (the same canonical sums as the state layout's)
         const D2 s1_ = fma2(-gam_w, egv, zv), s2_ = fma2(-gam_w, egw, zw);
         const D2 x1_ = D2{s1_.a - (inea ? clampd(s1_.a, vmin, vmax) : s1_.a), s1_.b - (ineb ? clampd(s1_.b, vmin, vmax) : s1_.b)};

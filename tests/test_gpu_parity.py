@@ -522,6 +522,58 @@ def test_circle_culling_is_exact(monkeypatch, name, B, radius):
     assert (cpu[2]["penalty"] > 1.0).any() and (cpu[2]["num_outer_iterations"] > 2).any()      # the circles did matter
 
 
+@pytest.mark.parametrize("shape", ["folded", "stationary", "far", "zigzag", "short"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "n6"])
+def test_windowed_cross_track_search_is_exact(name, shape):
+    """The three-point kernels measure only the segments around each stage's previous nearest segment and accept that only
+    if the rest of the reference is provably farther (eval_psi / eval_psi2, WIN); otherwise the full scan runs.  References
+    built to defeat the test -- a path folded back onto itself (zero clearance), a robot parked at the goal (all segments
+    the same point: every distance ties and the FIRST index must win), a robot 3 m off its path, a zig-zag whose far
+    corners come close again, horizons with fewer segments than a window -- give the oracle's bits."""
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = load_config(N_hor=6 if shape != "short" else 4, Nobs=3, Ndynobs=1) if name == "n6" else named_config(name)
+    if shape == "short" and name != "n6":
+        pytest.skip("window narrower than the table: the small-horizon case covers it")
+    B, N = 24, cfg.N_hor
+    P = synthetic_batch(cfg, 11, B, 77)
+    off_r = cfg.n_p - 3 * N
+    rng = np.random.default_rng(5)
+    for b in range(B):
+        x0, y0, th = P[b, 0], P[b, 1], P[b, 2]
+        step = 0.2 * (0.5 + rng.random())
+        k = np.arange(N)
+        if shape == "folded":            # out along the heading, back over the same points
+            along = step * np.where(k < N // 2, k, N - 1 - k)
+            rx, ry = x0 + along * np.cos(th), y0 + along * np.sin(th)
+        elif shape == "stationary":      # the reference pads with its last point near the goal (src/path_generator.py:328-331)
+            hold = rng.integers(0, N)
+            along = step * np.minimum(k, hold)
+            rx, ry = x0 + along * np.cos(th), y0 + along * np.sin(th)
+        elif shape == "far":             # the robot starts 3 m beside its path
+            rx = x0 + 3.0 * np.sin(th) + step * k * np.cos(th)
+            ry = y0 - 3.0 * np.cos(th) + step * k * np.sin(th)
+        elif shape == "zigzag":          # sharp corners every three samples, 0.3 m wide: far segments lie close together
+            side = 0.3 * ((k // 3) % 2)
+            rx = x0 + 0.05 * k * np.cos(th) - side * np.sin(th)
+            ry = y0 + 0.05 * k * np.sin(th) + side * np.cos(th)
+        else:
+            rx, ry = x0 + step * k * np.cos(th), y0 + step * k * np.sin(th)
+        P[b, off_r + 0:off_r + 3 * N:3] = rx
+        P[b, off_r + 1:off_r + 3 * N:3] = ry
+    s = BatchSolver(cfg, max_batch=B)
+    try:
+        gpu = s.solve(P)
+        u, y, _ = gpu
+        gpu2 = s.solve(P, u0=u, y0=y)                # warm restart: other centres, other trial points
+    finally:
+        s.close()
+    o = oracle_for(cfg)
+    cpu = o.solve_batch(P, threads=8)
+    assert_same_solution(gpu, cpu)
+    assert_same_solution(gpu2, o.solve_batch(P, u0=cpu[0], y0=cpu[1], threads=8))
+
+
 def test_results_do_not_depend_on_timing():
     """Helpers, migration and the work queue decide WHERE and WHEN work runs, never what comes out: repeated solves of the same
     batches -- sizes that put every instance in a team from the start, that mix owners and helpers, and that exceed the resident
