@@ -670,6 +670,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 #ifdef NMPC2_TICKS      // scripts/hyb2_sections.py: s_memtime ticks per section of a pass (fenced: upper bounds), reported in the status reals
         long long tk[5] = {0, 0, 0, 0, 0}, tkl = __builtin_amdgcn_s_memtime();
 #define NMPC2_TK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); tk[((i) + 4) % 5] += t_ - tkl; tkl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(NMPC_MARKS)  // section markers in the ISA dump (hipcc -S -DNMPC_MARKS)
+#define NMPC2_TK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define NMPC2_TK(i) do { } while (0)
 #endif
