@@ -53,7 +53,6 @@ struct LdsMap {
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x dyn_stride per-stage ellipse data
     int dyn_stride;  // columns per (ellipse, field): 24 / 32 for the three- / two-point layouts, N rounded up to even for one point
-    int win;     // hybrid kernel, windowed cross-track search: per window start, the squared distance from the window's anchor to the nearest segment outside it
     int req;     // hybrid kernel, team mode: the line-search request of this wave's instance -- u, r, d as 3 x 24 (v, w) pairs by stage
     int vec;     // 7 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed, grad at u_k
     int rho;     // m
@@ -154,7 +153,6 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     mp.dyn_stride = P == 64 ? ((N + 1) & ~1) : (P == 20 ? 24 : P);
     mp.dyn = o; o += NDYN_MAX * 6 * mp.dyn_stride;
     o = (o + 1) & ~1;
-    mp.win = o; o += P == 20 ? 2 * 24 : 0;           // per centre segment: anchor x | anchor y (its squared clearance rides in the segment's spare slot)
     mp.req = o; o += P == 20 ? TEAM_REQ_DOUBLES : 0;
     mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
     o = (o + 1) & ~1;                                 // 16-byte alignment for the double2 arrays
@@ -238,47 +236,24 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     NMPC_WAVE_SYNC();
 }
 
-// windowed cross-track search (eval_psi, WIN): for every segment c -- the previous arg-min of a lane -- the anchor A_c = its midpoint and the
-// squared distance from A_c to the nearest segment OUTSIDE the window around c (the window is clamped to the table at its ends; infinity if
-// nothing is outside); same distance formula as the search
+// Windowed cross-track search (eval_psi / eval_psi2, WIN > 0).  What a lane remembers from its last FULL scan of the reference segments:
+// the centre of its window, where the stage was then, and the squared distance from there to the nearest segment OUTSIDE the window
+// (0 = nothing known: the next evaluation scans everything).
+struct WinState {
+    int ctr;
+    double xr, yr, mo2;
+};
 #ifdef NMPC_WIN_STATS
-__device__ unsigned long long nmpc_win_stats[2];       // windowed searches | of which fell back to the full scan
+__device__ unsigned long long nmpc_win_stats[2];       // evaluations that tried the window | of which fell back to the full scan
 #endif
-// is the windowed minimum `best` (squared) the global one?  a2 = |p - A|^2, dlim = D^2
-__device__ __forceinline__ bool window_is_global(double a2, double best, double dlim)
+// Is the windowed minimum `best` (squared) the global one?  With a2 = |p - p_ref|^2 and mo2 = the squared clearance of the window at
+// p_ref, every segment outside the window is at least sqrt(mo2) - |p - p_ref| away from p (distances are 1-Lipschitz), so it is if
+// sqrt(best) + |p - p_ref| < sqrt(mo2)  <=>  t = mo2 - a2 - best > 0 and t^2 > 4 a2 best.  The margins (1e-5 relative on squared
+// distances) dwarf the rounding of the distance formula (<= 2e-10 relative wherever it matters; mo2 <= 1e-8 is stored as 0).
+__device__ __forceinline__ bool window_is_global(double a2, double best, double mo2)
 {
-#ifdef NMPC_WIN_GUARD_LOOSE
-    return 2.008 * (a2 + best) < dlim;                   // (|p - A| + d)^2 <= 2 (|p - A|^2 + d^2) < D^2
-#else
-    // |p - A| + d < D  <=>  D^2 - |p - A|^2 - d^2 > 2 |p - A| d, squared once more; margins for rounding on both tests
-    const double t = dlim - (a2 + best);
-    return t > 0.004 * dlim && t * t > 4.016 * (a2 * best);
-#endif
-}
-template <int WIN>
-__device__ __forceinline__ void window_table(lds_double *L, const LdsMap &mp, int N, int lane)
-{
-    const int nseg = N - 1;
-    if (nseg >= 2 * WIN + 1 && lane < nseg) {
-        int i0 = lane - WIN;
-        i0 = i0 < 0 ? 0 : (i0 > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0);
-        const lds_double *sc_ = L + mp.seg + SEG_STRIDE * lane;
-        const double Ax = fma(0.5, sc_[2], sc_[0]), Ay = fma(0.5, sc_[3], sc_[1]);
-        double dmin = __builtin_inf();
-        for (int i = 0; i < nseg; ++i) {
-            const lds_double *sg = L + mp.seg + SEG_STRIDE * i;
-            const double px = Ax - sg[0], py = Ay - sg[1];
-            const double dot = fma(px, sg[2], py * sg[3]);
-            const double tst = fmin(fmax(dot * sg[4], 0.0), 1.0);
-            const double ex = fma(tst, sg[2], -px), ey = fma(tst, sg[3], -py);
-            const double d2 = fma(ex, ex, ey * ey);
-            dmin = (i < i0 || i > i0 + 2 * WIN) ? fmin(dmin, d2) : dmin;
-        }
-        L[mp.win + lane] = Ax;
-        L[mp.win + 24 + lane] = Ay;
-        L[mp.seg + SEG_STRIDE * lane + 5] = dmin > 1e-8 ? dmin : 0.0;   // (the segment entries' spare sixth slot; a reference that folds back on itself gets no window)
-    }
-    NMPC_WAVE_SYNC();
+    const double t = mo2 - (a2 + best);
+    return t > 1e-5 * mo2 && t * t > 4.0001 * (a2 * best);
 }
 
 // the circles of an instance whose edge lies within `radius` of the start position (bit k = circle k); padding slots (r = 0) never are
@@ -311,7 +286,7 @@ template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, 
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
-                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, int *ctr = nullptr)
+                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, WinState *ws = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
@@ -356,47 +331,49 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     double best = __builtin_inf();
     int bi = 0;
     bool full_scan = true;
+    int i0c = 0;                        // first segment of the window the full scan measures the clearance of
     if constexpr (WIN > 0) {
-        // WINDOWED SEARCH (exact).  From one evaluation to the next a stage's nearest segment moves by a segment or two, so only the
-        // 2 WIN + 1 segments around the previous arg-min are measured -- per-lane LDS gathers instead of broadcasts -- and the result
-        // is accepted if it is PROVABLY the global one: with A the midpoint of the previous arg-min segment and D the distance from A
-        // to the nearest segment outside the window (table `win`, made at instance set-up), every outside segment is at least
-        // D - |p - A| away from p, so  |p - A| + d_window < D  rules them all out; tested without square roots as
-        // 2 (|p - A|^2 + d_window^2) < D^2, with 0.4 % margin for rounding.  If any stage
-        // of the wave fails the test the full scan below runs instead; either way `best`, `bi` are those of the full scan.
+        // WINDOWED SEARCH (exact).  From one evaluation to the next a stage's nearest segment rarely moves, so only the 2 WIN + 1
+        // segments around the lane's window centre are measured -- per-lane LDS gathers instead of broadcasts -- and the result is
+        // accepted if it is PROVABLY the full scan's (window_is_global above).  If any stage of the wave fails the test, or holds no
+        // clearance yet, the full scan below runs instead and renews every lane's clearance; either way `best`, `bi` are the full scan's.
         const int nseg = N - 1;
         if (nseg >= 2 * WIN + 1) {
-            int cc = *ctr;
+            int cc = ws->ctr;
             cc = cc < 0 ? 0 : (cc > nseg - 1 ? nseg - 1 : cc);
-            int i0 = cc - WIN;
-            i0 = i0 < 0 ? 0 : (i0 > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0);
-            const lds_double *sg = L + mp.seg + SEG_STRIDE * i0;
-            double wv[2 * WIN + 1][5];
+            i0c = cc - WIN;
+            i0c = i0c < 0 ? 0 : (i0c > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0c);
+            if (!__any(in_r && !(ws->mo2 > 0.0))) {
+                const lds_double *sg = L + mp.seg + SEG_STRIDE * i0c;
+                double wv[2 * WIN + 1][5];
 #pragma unroll
-            for (int j = 0; j <= 2 * WIN; ++j)
+                for (int j = 0; j <= 2 * WIN; ++j)
 #pragma unroll
-                for (int f = 0; f < 5; ++f) wv[j][f] = sg[j * SEG_STRIDE + f];
-            const lds_double *wt = L + mp.win + cc;
-            const double Ax = wt[0], Ay = wt[24], dlim = L[mp.seg + SEG_STRIDE * cc + 5];
+                    for (int f = 0; f < 5; ++f) wv[j][f] = sg[j * SEG_STRIDE + f];
 #pragma unroll
-            for (int j = 0; j <= 2 * WIN; ++j) {
-                const double px = xn - wv[j][0], py = yn - wv[j][1];
-                const double dot = fma(px, wv[j][2], py * wv[j][3]);
-                const double that = dot * wv[j][4];
-                const double tst = fmin(fmax(that, 0.0), 1.0);
-                const double ex = fma(tst, wv[j][2], -px), ey = fma(tst, wv[j][3], -py);
-                const double d2 = fma(ex, ex, ey * ey);
-                bi = d2 < best ? i0 + j : bi;
-                best = fmin(best, d2);
-            }
-            const double ax = xn - Ax, ay = yn - Ay;
-            const double a2 = fma(ax, ax, ay * ay);
-            const bool sure = window_is_global(a2, best, dlim);
-            full_scan = __any(in_r && !sure);
+                for (int j = 0; j <= 2 * WIN; ++j) {
+                    const double px = xn - wv[j][0], py = yn - wv[j][1];
+                    const double dot = fma(px, wv[j][2], py * wv[j][3]);
+                    const double that = dot * wv[j][4];
+                    const double tst = fmin(fmax(that, 0.0), 1.0);
+                    const double ex = fma(tst, wv[j][2], -px), ey = fma(tst, wv[j][3], -py);
+                    const double d2 = fma(ex, ex, ey * ey);
+                    bi = d2 < best ? i0c + j : bi;
+                    best = fmin(best, d2);
+                }
+                const double ax = xn - ws->xr, ay = yn - ws->yr;
+                const bool sure = window_is_global(fma(ax, ax, ay * ay), best, ws->mo2);
+                full_scan = __any(in_r && !sure);
 #ifdef NMPC_WIN_STATS
-            if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
+                if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
 #endif
-            if (full_scan) { best = __builtin_inf(); bi = 0; }
+                if (full_scan) {
+                    // the full scan measures the clearance of the window around what the old window found nearest
+                    i0c = bi - WIN;
+                    i0c = i0c < 0 ? 0 : (i0c > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0c);
+                    best = __builtin_inf(); bi = 0;
+                }
+            }
         }
     }
     if (full_scan) {
@@ -405,6 +382,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         // software pipeline: the ten LDS reads of the NEXT pair of segments are issued before the current
         // pair is reduced (the scheduling barriers keep the compiler from sinking them to their uses)
         double cur[2][5], nxt[2][5];
+        double mout = __builtin_inf();                      // (WIN) nearest segment outside the window [i0c, i0c + 2 WIN]
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -431,6 +409,10 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             for (int j = 0; j < 2; ++j) {                   // strict <: the first minimum keeps its index
                 bi = d2[j] < best ? i + j : bi;
                 best = fmin(best, d2[j]);
+                if constexpr (WIN > 0) {                    // (a padding entry repeats the last segment)
+                    const int ie = i + j < N - 1 ? i + j : N - 2;
+                    mout = (unsigned)(ie - i0c) <= 2u * WIN ? mout : fmin(mout, d2[j]);
+                }
             }
             NMPC_SCHED_BARRIER();
 #pragma unroll
@@ -438,8 +420,15 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
 #pragma unroll
                 for (int f = 0; f < 5; ++f) cur[j][f] = nxt[j][f];
         }
+        if constexpr (WIN > 0) {
+            // this lane's certificate for the evaluations to come: if the nearest segment lies in the window that was measured, the
+            // window stays and its clearance is known; if not, the window moves there and the next evaluation measures it
+            const bool inw = (unsigned)(bi - i0c) <= 2u * WIN;
+            ws->ctr = inw ? i0c + WIN : bi;
+            ws->xr = xn; ws->yr = yn;
+            ws->mo2 = inw && mout > 1e-8 ? mout : 0.0;
+        }
     }
-    if constexpr (WIN > 0) *ctr = bi;
     NMPC_EVTICK(1);     // stage cost + CTE loop
     acc = fma(sc[SC_QCTE], best, acc);                                            // (:144)
     // accelerations (:160-161), their cost (:170-171) and the ALM term

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         DynStage dyn;
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
-        if constexpr (WIN > 0) window_table<WIN>(L, mp, N, lane);
-        int ctr = te < N - 1 ? te : N - 2;          // centre of this lane's cross-track window: the last arg-min
+        WinState ws = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
+        if (lane == 0) Lpar[19] = (double)inst;                      // (helpers tell by it whether their own windows are still this instance's)
         unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
         if constexpr (CULL) {
             near = circle_near_mask(a.p + (size_t)inst * a.n_p, N, shape_nobs<SH>(a), lane, a.cull_radius);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zXv = lane_get(xv, zsrcX), zXw = lane_get(xw, zsrcX);
             const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ctr);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
@@ -799,7 +799,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
         ctl_add(ctl + CTL_HELPERS, 1);
     }
-    int ctr_h = te < N - 1 ? te : N - 2;          // this helper lane's window centre (a stale one only costs a full scan)
+    WinState ws_h = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this helper lane's cross-track window, valid for the instance `ws_inst`
+    double ws_inst = -1.0;
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         // claim the next open task of some sibling's request
@@ -835,7 +836,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         unsigned long long near_w = ~0ull;
         if constexpr (CULL) { const double nb_ = Lw[mp.par + 18]; near_w = ((unsigned long long)(unsigned)__double2hiint(nb_) << 32) | (unsigned)__double2loint(nb_); }
-        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ctr_h);
+        if constexpr (WIN > 0) {            // another instance's reference: what this lane knew about its window is void
+            const double inst_w = Lw[mp.par + 19];
+            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; }
+        }
+        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h);
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute
         const double gam_w = Lw[mp.par + 17];

@@ -74,7 +74,6 @@ struct LdsMap2 {
     int sc, cw, par, seg, obs, f2, rho;
     int dyn;      // NDYN_MAX x 6 x 48: [ellipse][field][stage]
     int vr;       // reference speed by stage (48)
-    int win;      // windowed cross-track search: anchor x | anchor y per centre segment (2 x 40), -1 if the slice has no room for it
     int pts;      // query points of a pass: X of half 0 | X of half 1 | Y, 24 entries of 4 doubles each
     int grd;      // gradients of the pass's three points, the same shape
     int req;      // team request: u | r | d, the same shape
@@ -83,7 +82,12 @@ struct LdsMap2 {
     int total;
 };
 #ifndef NMPC_WIN2
-#define NMPC_WIN2 2               // half width of the cross-track window of the two-stage kernel (measured: 1 -> 180.0, 2 -> 176.9 ms on config 2)
+// Half width of the cross-track window of the two-stage kernel.  Measured on config 2: 1 -> 177-179 ms, 0 (no windows) -> 196 ms.  Do NOT ship 2
+// with -amdgpu-sched-strategy=iterative-ilp: on ROCm 7.2 that combination of this kernel gives results that change from run to run (40 of 8192
+// instances of config 2; the same source under the default scheduler, or with NMPC_WIN2 = 1, or with the statistics counters compiled in, is exact and
+// repeatable) -- the second scheduler-dependent miscompilation of this 370-register kernel after max-ilp (csrc/Makefile).  The full-batch
+// permutation test (tests/test_gpu_fullbatch.py) is what catches such a build.
+#define NMPC_WIN2 1
 #endif
 constexpr int H2_COLS = 32, H2_NS = 21, H2_ENT = 24;
 constexpr int TEAM2_AREA_DOUBLES = 3 * H2_ENT * 4 + 8;
@@ -107,9 +111,6 @@ __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
     mp.vec = o; o += 7 * H2_COLS * 4;
     mp.S = o;   o += MAXMEM * H2_NS * 4;
     mp.Y = o;   o += MAXMEM * H2_NS * 4;
-    // the window table is taken only if four slices with it still fit a CU's LDS (N = 40 with more than ~55 circle slots does without)
-    mp.win = (size_t)(((o + 80 + 1) & ~1) * TEAM_WAVES) * sizeof(double) + TEAM_CTL_INTS * sizeof(int) <= 160 * 1024 && N <= 40 ? o : -1;
-    o += mp.win >= 0 ? 80 : 0;
     mp.total = (o + 1) & ~1;
     return mp;
 }
@@ -178,33 +179,6 @@ __device__ __forceinline__ void prepare_instance2(const KArgs &a, lds_double *L,
     NMPC_WAVE_SYNC();
 }
 
-// windowed cross-track search (nmpc_kernels.hip: window_table): per centre segment the anchor and the squared clearance of its window
-template <int WIN>
-__device__ __forceinline__ void window_table2(lds_double *L, const LdsMap2 &mp, int N, int lane)
-{
-    const int nseg = N - 1;
-    if (nseg >= 2 * WIN + 1 && mp.win >= 0 && lane < nseg) {
-        int i0 = lane - WIN;
-        i0 = i0 < 0 ? 0 : (i0 > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0);
-        const lds_double *sc_ = L + mp.seg + SEG_STRIDE * lane;
-        const double Ax = fma(0.5, sc_[2], sc_[0]), Ay = fma(0.5, sc_[3], sc_[1]);
-        double dmin = __builtin_inf();
-        for (int i = 0; i < nseg; ++i) {
-            const lds_double *sg = L + mp.seg + SEG_STRIDE * i;
-            const double px = Ax - sg[0], py = Ay - sg[1];
-            const double dot = fma(px, sg[2], py * sg[3]);
-            const double tst = fmin(fmax(dot * sg[4], 0.0), 1.0);
-            const double ex = fma(tst, sg[2], -px), ey = fma(tst, sg[3], -py);
-            const double d2 = fma(ex, ex, ey * ey);
-            dmin = (i < i0 || i > i0 + 2 * WIN) ? fmin(dmin, d2) : dmin;
-        }
-        L[mp.win + lane] = Ax;
-        L[mp.win + 40 + lane] = Ay;
-        L[mp.seg + SEG_STRIDE * lane + 5] = dmin > 1e-8 ? dmin : 0.0;
-    }
-    NMPC_WAVE_SYNC();
-}
-
 // this lane's two columns of a per-stage table of the ellipses
 __device__ __forceinline__ D2 dyn2(const lds_double *L, const LdsMap2 &mp, int te, int k, int f)
 {
@@ -219,7 +193,7 @@ __device__ __forceinline__ D2 dyn2(const lds_double *L, const LdsMap2 &mp, int t
 template <class SH, bool WRITE_F2 = false, int WIN = 0>
 __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const LdsMap2 &mp, int f2off, int lane, int te, D2 zv, D2 zw,
                                           double c, double cbar_inv, D2 yv, D2 yw, bool want_grad, double &psi, double &pen_out,
-                                          D2 &gv, D2 &gw, D2 &av_out, D2 &aw_out, int *ctr = nullptr)
+                                          D2 &gv, D2 &gw, D2 &av_out, D2 &aw_out, WinState *ws = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
@@ -262,53 +236,57 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
     D2 best = d2s(__builtin_inf());
     int bia = 0, bib = 0;
     bool full_scan = true;
+    int i0a = 0, i0b = 0;               // first segment of the window whose clearance the full scan measures, per stage
     if constexpr (WIN > 0) {
-        // windowed search around each stage's previous arg-min, accepted only if provably global (eval_psi in nmpc_kernels.hip has the argument)
+        // windowed search around each stage's window centre, accepted only if provably the full scan's (eval_psi in nmpc_kernels.hip
+        // has the argument): ws[0] belongs to stage a of this lane, ws[1] to stage b
         const int nseg = N - 1;
-        if (nseg >= 2 * WIN + 1 && mp.win >= 0) {
-            bool sure = true;
-#define NMPC2_WINDOW(S_, BI_, CTR_)                                                                        \
-            do {                                                                                           \
-                int cc = (CTR_);                                                                           \
-                cc = cc < 0 ? 0 : (cc > nseg - 1 ? nseg - 1 : cc);                                         \
-                int i0 = cc - WIN;                                                                         \
-                i0 = i0 < 0 ? 0 : (i0 > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0);                 \
-                const lds_double *sg = L + mp.seg + SEG_STRIDE * i0;                                       \
-                const lds_double *wt = L + mp.win + cc;                                                    \
-                const double Ax = wt[0], Ay = wt[40], dlim = L[mp.seg + SEG_STRIDE * cc + 5];              \
-                double bst = __builtin_inf();                                                              \
-                int bi_ = 0;                                                                               \
-                _Pragma("unroll") for (int j = 0; j <= 2 * WIN; ++j) {                                     \
-                    const double s0 = sg[j * SEG_STRIDE], s1 = sg[j * SEG_STRIDE + 1], s2 = sg[j * SEG_STRIDE + 2], \
-                                 s3 = sg[j * SEG_STRIDE + 3], s4 = sg[j * SEG_STRIDE + 4];                 \
-                    const double px = xn.S_ - s0, py = yn.S_ - s1;                                         \
-                    const double dot = fma(s2, px, s3 * py);                                               \
-                    const double tst = fmin(fmax(s4 * dot, 0.0), 1.0);                                     \
-                    const double ex = fma(s2, tst, -px), ey = fma(s3, tst, -py);                           \
-                    const double d2 = fma(ex, ex, ey * ey);                                                \
-                    bi_ = d2 < bst ? i0 + j : bi_;                                                         \
-                    bst = fmin(bst, d2);                                                                   \
-                }                                                                                          \
-                const double ax = xn.S_ - Ax, ay = yn.S_ - Ay;                                             \
-                sure = sure && window_is_global(fma(ax, ax, ay * ay), bst, dlim);                          \
-                best.S_ = bst; BI_ = bi_;                                                                  \
-            } while (0)
-            NMPC2_WINDOW(a, bia, ctr[0]);
-            const bool sure_a = sure;
-            sure = true;
-            NMPC2_WINDOW(b, bib, ctr[1]);
+        if (nseg >= 2 * WIN + 1) {
+#define NMPC2_CLAMP_WIN(C_) ((C_) - WIN < 0 ? 0 : ((C_) - WIN > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : (C_) - WIN))
+            { const int ca = ws[0].ctr < 0 ? 0 : (ws[0].ctr > nseg - 1 ? nseg - 1 : ws[0].ctr); i0a = NMPC2_CLAMP_WIN(ca); }
+            { const int cb = ws[1].ctr < 0 ? 0 : (ws[1].ctr > nseg - 1 ? nseg - 1 : ws[1].ctr); i0b = NMPC2_CLAMP_WIN(cb); }
+            if (!__any((ra && !(ws[0].mo2 > 0.0)) || (rb && !(ws[1].mo2 > 0.0)))) {
+                bool sure_a, sure_b;
+#define NMPC2_WINDOW(S_, BI_, I0_, WS_, SURE_)                                                             \
+                do {                                                                                       \
+                    const lds_double *sg = L + mp.seg + SEG_STRIDE * (I0_);                                \
+                    double bst = __builtin_inf();                                                          \
+                    int bi_ = 0;                                                                           \
+                    _Pragma("unroll") for (int j = 0; j <= 2 * WIN; ++j) {                                 \
+                        const double s0 = sg[j * SEG_STRIDE], s1 = sg[j * SEG_STRIDE + 1], s2 = sg[j * SEG_STRIDE + 2], \
+                                     s3 = sg[j * SEG_STRIDE + 3], s4 = sg[j * SEG_STRIDE + 4];             \
+                        const double px = xn.S_ - s0, py = yn.S_ - s1;                                     \
+                        const double dot = fma(s2, px, s3 * py);                                           \
+                        const double tst = fmin(fmax(s4 * dot, 0.0), 1.0);                                 \
+                        const double ex = fma(s2, tst, -px), ey = fma(s3, tst, -py);                       \
+                        const double d2 = fma(ex, ex, ey * ey);                                            \
+                        bi_ = d2 < bst ? (I0_) + j : bi_;                                                  \
+                        bst = fmin(bst, d2);                                                               \
+                    }                                                                                      \
+                    const double ax = xn.S_ - (WS_).xr, ay = yn.S_ - (WS_).yr;                             \
+                    SURE_ = window_is_global(fma(ax, ax, ay * ay), bst, (WS_).mo2);                        \
+                    best.S_ = bst; BI_ = bi_;                                                              \
+                } while (0)
+                NMPC2_WINDOW(a, bia, i0a, ws[0], sure_a);
+                NMPC2_WINDOW(b, bib, i0b, ws[1], sure_b);
 #undef NMPC2_WINDOW
-            full_scan = __any((ra && !sure_a) || (rb && !sure));
+                full_scan = __any((ra && !sure_a) || (rb && !sure_b));
 #ifdef NMPC_WIN_STATS
-            if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
+                if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
 #endif
-            if (full_scan) { best = d2s(__builtin_inf()); bia = bib = 0; }
+                if (full_scan) {            // the full scan measures the clearance of the windows around what the old windows found nearest
+                    i0a = NMPC2_CLAMP_WIN(bia); i0b = NMPC2_CLAMP_WIN(bib);
+                    best = d2s(__builtin_inf()); bia = bib = 0;
+                }
+            }
+#undef NMPC2_CLAMP_WIN
         }
     }
     if (full_scan) {
         const lds_double *sg = L + mp.seg;
         const int nseg4 = (N - 1 + 3) & ~3;
         double cur[2][5], nxt[2][5];
+        D2 mout = d2s(__builtin_inf());                     // (WIN) nearest segment outside each stage's window
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -336,6 +314,11 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
                 bia = d2v[j].a < best.a ? i + j : bia;
                 bib = d2v[j].b < best.b ? i + j : bib;
                 best = D2{fmin(best.a, d2v[j].a), fmin(best.b, d2v[j].b)};
+                if constexpr (WIN > 0) {                    // (a padding entry repeats the last segment)
+                    const int ie = i + j < N - 1 ? i + j : N - 2;
+                    mout.a = (unsigned)(ie - i0a) <= 2u * WIN ? mout.a : fmin(mout.a, d2v[j].a);
+                    mout.b = (unsigned)(ie - i0b) <= 2u * WIN ? mout.b : fmin(mout.b, d2v[j].b);
+                }
             }
             NMPC_SCHED_BARRIER();
 #pragma unroll
@@ -343,8 +326,12 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
 #pragma unroll
                 for (int f = 0; f < 5; ++f) cur[j][f] = nxt[j][f];
         }
+        if constexpr (WIN > 0) {            // each stage's certificate for the evaluations to come (eval_psi)
+            const bool inwa = (unsigned)(bia - i0a) <= 2u * WIN, inwb = (unsigned)(bib - i0b) <= 2u * WIN;
+            ws[0].ctr = inwa ? i0a + WIN : bia; ws[0].xr = xn.a; ws[0].yr = yn.a; ws[0].mo2 = inwa && mout.a > 1e-8 ? mout.a : 0.0;
+            ws[1].ctr = inwb ? i0b + WIN : bib; ws[1].xr = xn.b; ws[1].yr = yn.b; ws[1].mo2 = inwb && mout.b > 1e-8 ? mout.b : 0.0;
+        }
     }
-    if constexpr (WIN > 0) { ctr[0] = bia; ctr[1] = bib; }
     acc = fma2(sc[SC_QCTE], best, acc);                                           // (:144)
     // accelerations (:160-161), their cost (:170-171) and the ALM term
     D2 av = inv_ts * (zv - vprev), aw = inv_ts * (zw - wprev);
@@ -630,8 +617,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         if (inst < 0) break;
         const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
-        window_table2<NMPC_WIN2>(L, mp, N, lane);
-        int ctr[2] = {2 * te < N - 1 ? 2 * te : N - 2, 2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2};      // centres of this lane's cross-track windows
+        WinState ws[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // this lane's cross-track windows
+        if (lane == 0) Lpar[19] = (double)inst;              // (helpers tell by it whether their windows are still this instance's)
 
         const double *u0 = a.u + (size_t)inst * a.n_u;
         D2 uv = D2{ina ? u0[4 * t] : 0.0, inb ? u0[4 * t + 2] : 0.0}, uw = D2{ina ? u0[4 * t + 1] : 0.0, inb ? u0[4 * t + 3] : 0.0};
@@ -911,7 +898,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             ld4(Pts + 2 * (q * H2_ENT + te), zv, zw);
             ld4(Ly, yv, yw);
             NMPC2_TK(1);
-            eval_psi2<SH, false, NMPC_WIN2>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ctr);
+            eval_psi2<SH, false, NMPC_WIN2>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ws);
             NMPC2_TK(2);
             if (need_grad) st4(Grd + 2 * (q * H2_ENT + te), egv, egw);
             NMPC_WAVE_SYNC();
@@ -1132,7 +1119,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
         ctl_add(ctl + CTL_HELPERS, 1);
     }
-    int ctr_h[2] = {2 * te < N - 1 ? 2 * te : N - 2, 2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2};
+    WinState ws_h[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // valid for instance `ws_inst`
+    double ws_inst = -1.0;
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         int got = -1;
@@ -1163,7 +1151,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         const D2 zv = fma2(-tau_w, e1, fma2(-omt_w, r1, u1)), zw = fma2(-tau_w, e2, fma2(-omt_w, r2, u2));
         double psi, pen;
         D2 egv = d2s(0.0), egw = d2s(0.0), eav, eaw;
-        eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ctr_h);
+        {                                   // another instance's reference: what this lane knew about its windows is void
+            const double inst_w = Lw[mp.par + 19];
+            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; }
+        }
+        eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ws_h);
         // the trial's forward-backward envelope, in the evaluation layout (the same canonical sums as the state layout's)
         const D2 s1_ = fma2(-gam_w, egv, zv), s2_ = fma2(-gam_w, egw, zw);
         const D2 x1_ = D2{s1_.a - (inea ? clampd(s1_.a, vmin, vmax) : s1_.a), s1_.b - (ineb ? clampd(s1_.b, vmin, vmax) : s1_.b)};

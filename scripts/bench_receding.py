@@ -66,6 +66,11 @@ if not args.host:
     total = time.perf_counter() - t0
     done = np.concatenate([o[3] for o in outs])
     st = np.concatenate([o[4] for o in outs])
+    from mpc_trajectory_generator_amd import _lib
+    if hasattr(_lib.load_library(), "nmpc_debug_win_stats"):        # instrumented build (-DNMPC_WIN_STATS, scripts/win_stats.py)
+        buf = (ctypes.c_ulonglong * 2)()
+        _lib.load_library().nmpc_debug_win_stats(buf, 0)
+        print(f"windowed cross-track searches {buf[0]}, fell back {buf[1]} ({100.0 * buf[1] / max(buf[0], 1):.1f} %)", file=sys.stderr)
     print(json.dumps({
         "metric": "nmpc_receding_horizon_solves_per_sec", "value": B * (args.steps - 1) / total, "unit": "solves/s",
         "config": {"workload": f"cfg4 smooth_velocity, scene {args.scene}, B={B}, {args.steps} receding-horizon steps, "
