@@ -375,6 +375,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
             NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (SH::NOBS >= 0 && SH::NOBS <= 16 && k + j >= SH::NOBS) continue;      // (unrolled: the padding slots of a fixed shape cost nothing)
                 const D2 dx = xn - d2s(od[3 * j]), dy = yn - d2s(od[3 * j + 1]);
                 const D2 h = fma2(-dy, dy, fma2(-dx, dx, d2s(od[3 * j + 2])));    // (:112)
                 if (__any((ra && h.a > 0.0) || (rb && h.b > 0.0))) act |= 1ull << (k + j);
