@@ -25,6 +25,9 @@ done
 rocprofv3 --pmc $SQ1 -d "$OUT/pmc_team_sq" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_team_sq.log" 2>&1      # the same instance with its three helpers
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.log"
 for c in cfg2 cfg3 cfg4; do python bench.py --config $c --steps 3 --warmup 1 --no-pipelined > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.log"; done
+for c in cfg2 cfg3 cfg4; do      # the same kernel trace for the other BASELINE configurations
+    rocprofv3 --kernel-trace --stats -d "$OUT/trace_$c" -o trace --output-format csv -- python bench.py --config $c --steps 3 --warmup 1 --no-extras > "$OUT/bench_${c}_under_rocprof.json" 2> "$OUT/trace_$c.log"
+done
 python bench.py --config cfg3 --batch 65536 --steps 2 --warmup 1 --no-extras > "$OUT/bench_cfg3_64k.json" 2> "$OUT/bench_cfg3_64k.log"
 python bench.py --steps 5 --warmup 1 --budget 1500 --no-cpu-baseline > "$OUT/bench_budget1500.json" 2> "$OUT/bench_budget1500.log"
 NMPC_BENCH_FORCE_DIST=1 python bench.py --steps 5 --warmup 1 --no-extras > "$OUT/bench_rccl_world1.json" 2> "$OUT/bench_rccl_world1.log"

@@ -14,6 +14,11 @@ if cands:
     rows = list(csv.reader(open(cands[0])))
     with open(os.path.join(out, "kernel_stats.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(rows)
+for c in ("cfg2", "cfg3", "cfg4"):
+    cands = glob.glob(os.path.join(out, f"trace_{c}", "**", "*kernel_stats.csv"), recursive=True)
+    if cands:
+        with open(os.path.join(out, f"kernel_stats_{c}.csv"), "w", newline="") as fh:
+            csv.writer(fh).writerows(list(csv.reader(open(cands[0]))))
 per_kernel = {}
 for name in ("fetch", "write", "sq", "wait", "lone_sq", "lone_wait", "team_sq", "cfg2_sq"):
     files = glob.glob(os.path.join(out, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)
