@@ -17,6 +17,10 @@
 #include <string>
 #include <vector>
 
+#ifndef NMPC_WIN
+#define NMPC_WIN 1      // half width of the cross-track window of the one-stage-per-lane kernels (eval_psi); 0 = always the full scan
+#endif
+
 namespace nmpc {
 
 constexpr int NZ = 20;         // reference configs/default.yaml:35
@@ -695,6 +699,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
     int state = ST_IDLE, inst = -1;
     bool done = false;                       // queue exhausted for this group
     double vref = 0.0;
+    WinState ws = {0, 0.0, 0.0, 0.0};        // this lane's cross-track window (eval_psi, WIN)
     DynStage dyn;
     dyn.col = L + mp.dyn + t;
     dyn.stride = P == 64 ? mp.dyn_stride : P;
@@ -731,6 +736,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
                 t_start = (long long)__builtin_amdgcn_s_memrealtime();
                 n_pass = 0;
                 prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+                ws = WinState{t < N - 1 ? t : N - 2, 0.0, 0.0, 0.0};       // this lane's cross-track window: nothing known yet
                 const double *u0 = a.u + (size_t)inst * a.n_u;
                 uv = in ? u0[2 * t] : 0.0;
                 uw = in ? u0[2 * t + 1] : 0.0;
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
         // ------------------------------------------------------------------ one evaluation of psi per group
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         const bool wg = __any(live && need_grad);
-        eval_psi<P, SH>(a, L, mp.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw);
+        eval_psi<P, SH, false, false, NMPC_WIN>(a, L, mp.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw, ~0ull, &ws);
         if (!live) continue;
         n_pass++;
 

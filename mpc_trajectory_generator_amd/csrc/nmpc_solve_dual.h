@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
         double vref;
         DynStage dyn;
         prepare_instance<P>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
+        WinState ws = {t < N - 1 ? t : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
 
         // horizon vectors: lane t holds the (v_t, w_t) pair, identically in both halves unless noted
         const double *u0 = a.u + (size_t)inst * a.n_u;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64, 2) void nmpc_solve_dual_kernel(KArgs a)
 #ifdef NMPC_PROFILE
             NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
 #endif
-            eval_psi<P>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw);
+            eval_psi<P, ShapeAny, false, false, NMPC_WIN>(a, L, f2off, lane, t, zv, zw, pen_c, cbar_inv, yv, yw, vref, dyn, need_grad, psi, pen, egv, egw, eav, eaw, ~0ull, &ws);
 #ifdef NMPC_PROFILE
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
             NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
