@@ -26,7 +26,7 @@ namespace nmpc {
 constexpr int NZ = 20;         // reference configs/default.yaml:35
 constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
 constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
-constexpr int SEG_STRIDE = 6;  // doubles per reference segment in LDS
+constexpr int SEG_STRIDE = 5;  // doubles per reference segment in LDS (odd: the per-lane window gathers of eval_psi spread over all banks)
 // team mode of the hybrid kernel (nmpc_solve_hyb.h): four waves per workgroup; a wave without work of its own evaluates
 // line-search trials for its siblings.  Request = u, r, d by stage (3 x 24 pairs); one result area = three trials'
 // gradients by stage (3 x 24 pairs) + their psi values
