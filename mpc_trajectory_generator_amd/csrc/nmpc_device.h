@@ -62,14 +62,33 @@ __device__ __forceinline__ int lane_get_i(int v, int src_lane)
     return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
 }
 
-// v_permlane16_swap: exchanges odd rows of the first operand with even rows of the second.
-// swap(x, x) -> first = [r0 r0 r2 r2], second = [r1 r1 r3 r3] (rows of 16 lanes)
-__device__ __forceinline__ void row_pair_split(double v, double &even_rows, double &odd_rows)
+// v_permlane16_swap / v_permlane32_swap rewrite BOTH their operands, so "the value of the other row / half" needs the value in two
+// registers.  They are never handed the same value twice (swap(x, x)): ROCm 7.2's register coalescer then joins the copy with x into one
+// wide virtual register and leaves a read-undef flag on the swap's tied second def that declares the other lanes of x dead, and a
+// scheduler that moves the copy above the instruction producing x (-amdgpu-sched-strategy=max-ilp does) swaps a stale register -- wrong
+// results that depend on what ran before (scripts/check_sched.py finds both the flag and the move).  Instead the
+// second register is a full 64-bit definition of its own: the producing addition issued twice (one v_add_f64 instead of the two v_mov_b32
+// of a copy -- `opaque` keeps the compiler from merging them), or an opaque copy where there is no producing instruction to repeat.
+__device__ __forceinline__ double opaque(double x)
 {
-    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-    even_rows = __hiloint2double(hi[0], lo[0]);
-    odd_rows = __hiloint2double(hi[1], lo[1]);
+    asm("" : "+v"(x));
+    return x;
+}
+// a <- [a.r0 b.r0 a.r2 b.r2], b <- [a.r1 b.r1 a.r3 b.r3] (rows of 16 lanes): odd rows of a change places with even rows of b
+__device__ __forceinline__ void swap_rows(double &a, double &b)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+// a <- [a.h0 b.h0], b <- [a.h1 b.h1] (halves of 32 lanes)
+__device__ __forceinline__ void swap_halves(double &a, double &b)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
 }
 
 // bitwise OR over all 64 lanes, returned as a wave-uniform scalar
@@ -86,25 +105,29 @@ __device__ __forceinline__ unsigned wave_or(unsigned v)
 
 // sum over the P lanes of the group, result in every lane.  Butterfly over lane^1, ^2, ^4, ^8, ^16
 // (^32); a + b == b + a bitwise, so every lane ends with the value of the adjacent-pair tree.
+// the sum over the 32 lanes of each half in TWO registers (every lane of a half holds its half's sum in both)
+__device__ __forceinline__ void half_sum_twice(double v, double &s1, double &s2)
+{
+    v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = v + dpp_mov<0x141>(v);      // row_half_mirror: the other quad of the 8-lane block
+    const double o = dpp_mov<0x140>(v);      // row_mirror: the other 8-lane block of the row
+    double a = v + o, b = v + opaque(o);
+    swap_rows(a, b);                // a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]: the other row of the 32-lane half
+    s1 = a + b;
+    s2 = a + opaque(b);
+}
 template <int P>
 __device__ __forceinline__ double group_sum(double v, int lane)
 {
     (void)lane;
-    v = v + dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = v + dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = v + dpp_mov<0x141>(v);      // row_half_mirror: the other quad of the 8-lane block
-    v = v + dpp_mov<0x140>(v);      // row_mirror: the other 8-lane block of the row
-    {
-        double a, b;
-        row_pair_split(v, a, b);    // the other row of the 32-lane half
-        v = a + b;
-    }
+    double s1, s2;
+    half_sum_twice(v, s1, s2);
     if (P == 64) {
-        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+        swap_halves(s1, s2);        // s1 = [h0 h0], s2 = [h1 h1]
+        return s1 + s2;
     }
-    return v;
+    return s1;
 }
 
 // inclusive prefix sum over the stages of the group: Kogge-Stone inside 16-lane rows, then carries

@@ -17,13 +17,14 @@
 
 namespace nmpc {
 
-// value held by the same stage in half 0 / half 1, delivered to both halves
+// value held by the same stage in half 0 / half 1, delivered to both halves (the second register of the swap is an opaque copy:
+// swap_halves in nmpc_device.h has the reason)
 __device__ __forceinline__ void both_halves(double v, double &from_h0, double &from_h1)
 {
-    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-    from_h0 = __hiloint2double(hi[0], lo[0]);
-    from_h1 = __hiloint2double(hi[1], lo[1]);
+    double a = v, b = opaque(v);
+    swap_halves(a, b);
+    from_h0 = a;
+    from_h1 = b;
 }
 
 enum : int { D_INIT = 0, D_LIP, D_ITER, D_LS, D_ALM, D_FB };
@@ -41,8 +42,11 @@ __device__ __forceinline__ dbl2 ld_pair(const lds_double2 *base, int idx, bool k
 // to every lane.  Same bits as two separate group_sum<32>.
 __device__ __forceinline__ void pair_sum(double a, double b, int lane, double &sum_a, double &sum_b)
 {
-    const double s = group_sum<32>((lane & 32) ? b : a, lane);
-    both_halves(s, sum_a, sum_b);
+    double s1, s2;
+    half_sum_twice((lane & 32) ? b : a, s1, s2);
+    swap_halves(s1, s2);
+    sum_a = s1;
+    sum_b = s2;
 }
 
 // forward-backward envelope at the point whose cost / gradient / gradient step / half step are given

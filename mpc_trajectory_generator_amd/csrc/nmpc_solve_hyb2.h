@@ -942,6 +942,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             } else if (state == D_LIP || state == D_ITER) {
                 n_cost++;
                 const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - gr + c_lip * nr2;
+#ifdef NMPC2_DEBUG_LIP      /* experiments: the operands of the first Lipschitz tests of instance 0, into y_out of the LAST instance */
+                if (inst == 0 && n_cost <= 4u && lane == 0 && a.y_out) {
+                    double *dbg_ = a.y_out + (size_t)(a.B - 1) * a.n1 + 8 * (n_cost - 1u);
+                    dbg_[0] = cost; dbg_[1] = gr; dbg_[2] = nr2; dbg_[3] = c_lip; dbg_[4] = psiA; dbg_[5] = rhs; dbg_[6] = gamma; dbg_[7] = Lc;
+                }
+#endif
                 if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
                     f_back = true;
                 } else {
