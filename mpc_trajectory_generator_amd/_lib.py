@@ -6,6 +6,7 @@ impossible or no MI355X is visible the constructor of the solver raises.
 from __future__ import annotations
 
 import ctypes as C
+import json
 import os
 import subprocess
 
@@ -13,6 +14,7 @@ import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libnmpc_hip.so")
+BUILD_INFO = os.path.join(_CSRC, "build_info.json")      # written by build_library: flags, codegen check, registers / LDS / scratch per kernel
 
 # every symbol include/nmpc_solver.h declares
 SYMBOLS = (
@@ -112,10 +114,65 @@ def build_library(force: bool = False) -> str:
                 r = subprocess.run(["make", "-C", _CSRC, "-B", tmp, f"OUT={tmp}"], capture_output=True, text=True)
                 if r.returncode != 0:
                     raise RuntimeError("building libnmpc_hip.so failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+                # the compiler's output is checked before it is accepted: ROCm 7.2 has produced silently wrong code for these kernels twice
+                # (codegen_check.py); the verdict, the flags and the kernels' resources go to build_info.json, which bench.py quotes
+                from . import codegen_check
+                res = codegen_check.verify()
+                info = {"source_hash": source_hash(), "flags": res.get("flags"), "codegen_check": {k: v for k, v in res.items() if k != "resources"},
+                        "resources": res.get("resources", {})}
+                with open(BUILD_INFO, "w") as fh:
+                    json.dump(info, fh, indent=1)
+                if not res["ok"]:
+                    os.remove(os.path.join(_CSRC, tmp))
+                    raise RuntimeError("libnmpc_hip.so REFUSED: the compiler generated wrong code for these flags (codegen_check): " +
+                                       json.dumps(info["codegen_check"])[:3000])
                 os.replace(os.path.join(_CSRC, tmp), LIB_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
+
+
+# The same sources under the other machine-scheduler strategies: not shipped, but built and run by tests/test_gpu_strategies.py -- a kernel
+# whose results depend on the schedule has a defect (or the compiler has: codegen_check.py), and the shipped strategy may only be hiding it.
+STRATEGIES = {"default": [], "max-memory-clause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+              "max-ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(_CSRC, "variants", f"libnmpc_{name}.so")
+
+
+def build_variant(name: str, force: bool = False) -> dict:
+    """Build csrc/variants/libnmpc_<name>.so with strategy `name` and run the code-generation check on it; -> that check's result."""
+    from . import codegen_check
+    flags = STRATEGIES[name]
+    out, meta = variant_path(name), variant_path(name)[:-3] + ".json"
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if os.path.exists(out) and os.path.exists(meta) and not force:      # fresh = built from these very sources (content, not time stamps)
+        with open(meta) as fh:
+            res = json.load(fh)
+        if res.get("source_hash") == source_hash():
+            return res
+    r = subprocess.run(["make", "-C", _CSRC, "-B", os.path.relpath(out, _CSRC), f"OUT={os.path.relpath(out, _CSRC)}", "SCHED=" + " ".join(flags)],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building {out} failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+    res = codegen_check.verify(flags)
+    res.pop("resources", None)
+    res["source_hash"] = source_hash()
+    with open(meta, "w") as fh:
+        json.dump(res, fh)
+    return res
+
+
+def build_info() -> dict:
+    """What the library in use was built with (flags, code-generation check, resources per kernel); {} for a library of unknown origin."""
+    try:
+        with open(BUILD_INFO) as fh:
+            info = json.load(fh)
+        return info if info.get("source_hash") == source_hash() else {"stale": True, **info}
+    except OSError:
+        return {}
 
 
 _lib = None

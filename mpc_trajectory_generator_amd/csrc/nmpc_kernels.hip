@@ -52,7 +52,7 @@ struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
     int par;     // up to 20 parked solver scalars (hybrid kernel)
-    int seg;     // 6 per reference segment (48 B): s1x s1y dx dy inv pad
+    int seg;     // SEG_STRIDE = 5 per reference segment (40 B): s1x s1y dx dy 1/(|d|^2 + 1e-16)
     int obs;     // 3 per static circle: xs ys r^2
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x dyn_stride per-stage ellipse data
@@ -164,6 +164,9 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     mp.S = o;   o += 2 * ring * MAXMEM;
     mp.Y = o;   o += 2 * ring * MAXMEM;
     mp.total = (o + 1) & ~1;
+    // team mode: a helper wave's slice holds one result area per (owner, task) from offset 0 -- twelve of them; short horizons make slices
+    // smaller than that (N_hor <= 14), and an area past the slice would land in the next wave's tables
+    if (P == 20 && mp.total < 3 * TEAM_WAVES * TEAM_AREA_DOUBLES) mp.total = 3 * TEAM_WAVES * TEAM_AREA_DOUBLES;
     return mp;
 }
 // the map a kernel instantiation works with: compile-time for a fixed shape, the launch argument otherwise
@@ -347,7 +350,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             cc = cc < 0 ? 0 : (cc > nseg - 1 ? nseg - 1 : cc);
             i0c = cc - WIN;
             i0c = i0c < 0 ? 0 : (i0c > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : i0c);
-            if (!__any(in_r && !(ws->mo2 > 0.0))) {
+            if (!__any(in_r & !(ws->mo2 > 0.0))) {
                 const lds_double *sg = L + mp.seg + SEG_STRIDE * i0c;
                 double wv[2 * WIN + 1][5];
 #pragma unroll
@@ -367,7 +370,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                 }
                 const double ax = xn - ws->xr, ay = yn - ws->yr;
                 const bool sure = window_is_global(fma(ax, ax, ay * ay), best, ws->mo2);
-                full_scan = __any(in_r && !sure);
+                full_scan = __any(in_r & !sure);
 #ifdef NMPC_WIN_STATS
                 if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
 #endif
@@ -475,7 +478,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             if (todo != all) {
                 const double rx = xn - x0, ry = yn - y0;
                 const double rg = 0.999 * a.cull_radius;
-                if (__any(in_r && !(fma(rx, rx, ry * ry) <= rg * rg))) todo = all;
+                if (__any(in_r & !(fma(rx, rx, ry * ry) <= rg * rg))) todo = all;
             }
             while (todo) {                                  // four circles per trip; slot `nobs` holds an inert zero circle
                 int kk[4];
@@ -495,7 +498,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                 for (int j = 0; j < 4; ++j) {
                     const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
                     const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
-                    if (__any(in_r && h > 0.0)) act |= 1ull << (kk[j] & 63);          // (the inert circle never is)
+                    if (__any(in_r & (h > 0.0))) act |= 1ull << (kk[j] & 63);          // (the inert circle never is)
                 }
             }
         } else {
@@ -509,7 +512,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             for (int j = 0; j < 4; ++j) {
                 const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
                 const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
-                if (__any(in_r && h > 0.0)) act |= 1ull << (k + j);
+                if (__any(in_r & (h > 0.0))) act |= 1ull << (k + j);
             }
         }
         }
@@ -531,7 +534,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                     const double eb = fma(dx, sa, -(dy * ca));
                     const double h = fma(-(eb * eb), dv_[k][DY_IRY2], fma(-(ea * ea), dv_[k][DY_IRX2], 1.0));   // (:118)
                     dyh[k] = in ? fmax(h, 0.0) : 0.0;
-                    if (__any(in_r && dyh[k] > 0.0)) act_dyn |= 1u << k;
+                    if (__any(in_r & (dyh[k] > 0.0))) act_dyn |= 1u << k;
                 }
             }
         }
@@ -1159,6 +1162,7 @@ struct nmpc_handle {
     double *d_p, *d_u, *d_y0, *d_c0, *d_yout, *d_psi, *d_grad, *d_F1, *d_F2;
     char *h_pin[2];            // pinned bounce buffers of the host entry points (pageable user memory <-> HBM at DMA speed)
     hipEvent_t pin_ev[2];
+    bool staging_ready;        // every staging resource above exists
     nmpc_status *d_st;
     std::string err;
 };
@@ -1253,7 +1257,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->d_order = nullptr;
     h->d_cls = nullptr;
     h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
-    h->h_pin[0] = h->h_pin[1] = nullptr; h->pin_ev[0] = h->pin_ev[1] = nullptr;
+    h->h_pin[0] = h->h_pin[1] = nullptr; h->pin_ev[0] = h->pin_ev[1] = nullptr; h->staging_ready = false;
     h->d_st = nullptr;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_queue, sizeof(unsigned int));
@@ -1444,7 +1448,8 @@ int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const doubl
 static constexpr size_t PIN_CHUNK = 4u << 20;
 static int ensure_staging(nmpc_handle *h)
 {
-    if (h->d_p) return NMPC_OK;
+    if (h->staging_ready) return NMPC_OK;
+    if (h->d_p) return fail(h, NMPC_ERR_HIP, "staging buffers: an earlier allocation failed half way");
     const size_t B = (size_t)h->max_batch;
     const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb), n2 = nmpc_n2(&h->pb) + 1;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1462,6 +1467,7 @@ static int ensure_staging(nmpc_handle *h)
         HIP_TRY(h, hipHostMalloc((void **)&h->h_pin[k], PIN_CHUNK, hipHostMallocDefault));
         HIP_TRY(h, hipEventCreateWithFlags(&h->pin_ev[k], hipEventDisableTiming));
     }
+    h->staging_ready = true;
     return NMPC_OK;
 }
 
@@ -1555,10 +1561,10 @@ int nmpc_eval_batch_host(nmpc_handle *h, int B, const double *p, const double *u
     int rc = ensure_staging(h);
     if (rc) return rc;
     const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb), n2 = nmpc_n2(&h->pb);
-    HIP_TRY(h, hipMemcpy(h->d_p, p, B * np * 8, hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_u, u, B * nu * 8, hipMemcpyHostToDevice));
-    if (y) HIP_TRY(h, hipMemcpy(h->d_y0, y, B * n1 * 8, hipMemcpyHostToDevice));
-    if (c) HIP_TRY(h, hipMemcpy(h->d_c0, c, B * 8, hipMemcpyHostToDevice));
+    HIP_TRY(h, h2d_staged(h, h->d_p, p, B * np * 8));
+    HIP_TRY(h, h2d_staged(h, h->d_u, u, B * nu * 8));
+    if (y) HIP_TRY(h, h2d_staged(h, h->d_y0, y, B * n1 * 8));
+    if (c) HIP_TRY(h, h2d_staged(h, h->d_c0, c, B * 8));
     rc = nmpc_eval_batch_device(h, B, h->d_p, h->d_u, c ? h->d_c0 : nullptr, y ? h->d_y0 : nullptr, h->d_psi,
                                 h->d_grad, h->d_F1, h->d_F2, nullptr);
     if (rc) return rc;

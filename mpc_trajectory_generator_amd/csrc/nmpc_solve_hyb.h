@@ -208,6 +208,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         if (a.dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
         DynStage dyn;
+        // (the instance id goes away BEFORE the tables change and comes back after: a helper still evaluating a cancelled request of the previous
+        // instance then finds another id after its evaluation than before it and throws away what it learnt about its window)
+        if (lane == 0) Lpar[19] = -1.0;
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
         WinState ws = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
@@ -841,6 +844,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; }
         }
         eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h);
+        if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
+            if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; }
+        }
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute
         const double gam_w = Lw[mp.par + 17];

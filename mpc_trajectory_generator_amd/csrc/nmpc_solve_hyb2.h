@@ -82,11 +82,9 @@ struct LdsMap2 {
     int total;
 };
 #ifndef NMPC_WIN2
-// Half width of the cross-track window of the two-stage kernel.  Measured on config 2: 1 -> 177-179 ms, 0 (no windows) -> 196 ms.  Do NOT ship 2
-// with -amdgpu-sched-strategy=iterative-ilp: on ROCm 7.2 that combination of this kernel gives results that change from run to run (40 of 8192
-// instances of config 2; the same source under the default scheduler, or with NMPC_WIN2 = 1, or with the statistics counters compiled in, is exact and
-// repeatable) -- the second scheduler-dependent miscompilation of this 370-register kernel after max-ilp (csrc/Makefile).  The full-batch
-// permutation test (tests/test_gpu_fullbatch.py) is what catches such a build.
+// Half width of the cross-track window of the two-stage kernel.  Measured on config 2: 1 -> 174-179 ms, 2 -> 176-180 ms, 0 (no windows) -> 196 ms.
+// (Round 3 saw a W = 2 build whose results changed from run to run and blamed the window.  The cause was the compiler: register-allocator copies
+// in front of an EXEC restore, codegen_check.py; W = 2 is exact and repeatable under all four scheduler strategies, only not faster.)
 #define NMPC_WIN2 1
 #endif
 constexpr int H2_COLS = 32, H2_NS = 21, H2_ENT = 24;
@@ -245,7 +243,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
 #define NMPC2_CLAMP_WIN(C_) ((C_) - WIN < 0 ? 0 : ((C_) - WIN > nseg - (2 * WIN + 1) ? nseg - (2 * WIN + 1) : (C_) - WIN))
             { const int ca = ws[0].ctr < 0 ? 0 : (ws[0].ctr > nseg - 1 ? nseg - 1 : ws[0].ctr); i0a = NMPC2_CLAMP_WIN(ca); }
             { const int cb = ws[1].ctr < 0 ? 0 : (ws[1].ctr > nseg - 1 ? nseg - 1 : ws[1].ctr); i0b = NMPC2_CLAMP_WIN(cb); }
-            if (!__any((ra && !(ws[0].mo2 > 0.0)) || (rb && !(ws[1].mo2 > 0.0)))) {
+            if (!__any((ra & !(ws[0].mo2 > 0.0)) | (rb & !(ws[1].mo2 > 0.0)))) {      // (& |, not && ||: lane masks, no divergent branches)
                 bool sure_a, sure_b;
 #define NMPC2_WINDOW(S_, BI_, I0_, WS_, SURE_)                                                             \
                 do {                                                                                       \
@@ -270,7 +268,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
                 NMPC2_WINDOW(a, bia, i0a, ws[0], sure_a);
                 NMPC2_WINDOW(b, bib, i0b, ws[1], sure_b);
 #undef NMPC2_WINDOW
-                full_scan = __any((ra && !sure_a) || (rb && !sure_b));
+                full_scan = __any((ra & !sure_a) | (rb & !sure_b));
 #ifdef NMPC_WIN_STATS
                 if (lane == 0) { atomicAdd(&nmpc_win_stats[0], 1ull); if (full_scan) atomicAdd(&nmpc_win_stats[1], 1ull); }
 #endif
@@ -378,7 +376,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
                 if (SH::NOBS >= 0 && SH::NOBS <= 16 && k + j >= SH::NOBS) continue;      // (unrolled: the padding slots of a fixed shape cost nothing)
                 const D2 dx = xn - d2s(od[3 * j]), dy = yn - d2s(od[3 * j + 1]);
                 const D2 h = fma2(-dy, dy, fma2(-dx, dx, d2s(od[3 * j + 2])));    // (:112)
-                if (__any((ra && h.a > 0.0) || (rb && h.b > 0.0))) act |= 1ull << (k + j);
+                if (__any((ra & (h.a > 0.0)) | (rb & (h.b > 0.0)))) act |= 1ull << (k + j);
             }
         }
 #pragma unroll
@@ -391,7 +389,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
                 const D2 eb = fma2(dx, sa, -(dy * ca));
                 const D2 h = fma2(-(eb * eb), dyn2(L, mp, te, k, DY_IRY2), fma2(-(ea * ea), dyn2(L, mp, te, k, DY_IRX2), d2s(1.0)));   // (:118)
                 dyh[k] = D2{ina ? fmax(h.a, 0.0) : 0.0, inb ? fmax(h.b, 0.0) : 0.0};
-                if (__any((ra && dyh[k].a > 0.0) || (rb && dyh[k].b > 0.0))) act_dyn |= 1u << k;
+                if (__any((ra & (dyh[k].a > 0.0)) | (rb & (dyh[k].b > 0.0)))) act_dyn |= 1u << k;
             }
         }
     }
@@ -617,6 +615,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         const int inst = __builtin_amdgcn_readfirstlane(fetched);
         if (inst < 0) break;
         const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
+        if (lane == 0) Lpar[19] = -1.0;                      // (nmpc_solve_hyb.h: the id is away while the tables change)
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
         WinState ws[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // this lane's cross-track windows
         if (lane == 0) Lpar[19] = (double)inst;              // (helpers tell by it whether their windows are still this instance's)
@@ -864,7 +863,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 uv = hv; uw = hw;                                        // PANOC returns the feasible half step
                 const bool fin = __builtin_isfinite(uv.a) && __builtin_isfinite(uw.a) && __builtin_isfinite(uv.b) && __builtin_isfinite(uw.b) &&
                                  __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
-                if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
+                if (__any(in & !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
                 else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
             }
             // ---------------------------------------------------------------- start an inner solve
@@ -942,13 +941,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             } else if (state == D_LIP || state == D_ITER) {
                 n_cost++;
                 const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - gr + c_lip * nr2;
-#ifdef NMPC2_DEBUG_LIP      /* experiments: the operands of the first Lipschitz tests of instance 0, into y_out of the LAST instance */
-                if (inst == 0 && n_cost <= 4u && lane == 0 && a.y_out) {
-                    double *dbg_ = a.y_out + (size_t)(a.B - 1) * a.n1 + 8 * (n_cost - 1u);
-                    dbg_[0] = cost; dbg_[1] = gr; dbg_[2] = nr2; dbg_[3] = c_lip; dbg_[4] = psiA; dbg_[5] = rhs; dbg_[6] = gamma; dbg_[7] = Lc;
-                }
-#endif
-                if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any(Lc < MAX_LIPSCHITZ_CONSTANT && psiA > rhs)) {
+                if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && __any((Lc < MAX_LIPSCHITZ_CONSTANT) & (psiA > rhs))) {
                     f_back = true;
                 } else {
                     if (state == D_LIP) {
@@ -1163,6 +1156,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; }
         }
         eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ws_h);
+        if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; }      // (the owner moved on meanwhile)
         // the trial's forward-backward envelope, in the evaluation layout (the same canonical sums as the state layout's)
         const D2 s1_ = fma2(-gam_w, egv, zv), s2_ = fma2(-gam_w, egw, zw);
         const D2 x1_ = D2{s1_.a - (inea ? clampd(s1_.a, vmin, vmax) : s1_.a), s1_.b - (ineb ? clampd(s1_.b, vmin, vmax) : s1_.b)};

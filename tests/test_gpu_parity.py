@@ -482,6 +482,29 @@ def test_team_modes_same_bits(monkeypatch, name, B, env):
     assert_same_solution(gpu2, o.solve_batch(P, u0=cpu[0], y0=cpu[1], threads=8))
 
 
+@pytest.mark.parametrize("shape", [(5, 1, 3), (2, 0, 0), (10, 10, 0), (14, 0, 0)], ids=lambda s: "N%d-obs%d-dyn%d" % s)
+def test_four_owners_on_short_horizons(monkeypatch, shape):
+    """Short horizons make the LDS slice of a wave smaller than the twelve result areas a helper keeps in its own slice (N_hor <= 14):
+    with four owners per workgroup a helper's areas for owner 3 then landed in the next wave's tables (round-3 advisor).  lds_layout
+    now sizes the slice for the areas; enough instances here that waves finish at different times and help each other."""
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    N, nobs, ndyn = shape
+    cfg = load_config(N_hor=N, Nobs=nobs, Ndynobs=ndyn)
+    P = synthetic_batch(cfg, 11, 96, 4242, random_dyn=ndyn > 0)
+    monkeypatch.setenv("NMPC_TEAM_OWNERS", "4")
+    s = BatchSolver(cfg, max_batch=96)
+    try:
+        gpu = s.solve(P)
+        gpu2 = s.solve(P, u0=gpu[0], y0=gpu[1])
+    finally:
+        s.close()
+    o = oracle_for(cfg)
+    cpu = o.solve_batch(P, threads=8)
+    assert_same_solution(gpu, cpu)
+    assert_same_solution(gpu2, o.solve_batch(P, u0=cpu[0], y0=cpu[1], threads=8))
+
+
 def test_team_switches_and_budget_bit_exact(monkeypatch):
     """Line-search exhaustion (ls_failure = 1: the eleventh trial comes from a helper's result area), the per-trial
     AKKT gradient cache and the iteration budget, with helpers from the first iteration on."""
