@@ -88,6 +88,22 @@ def flop_model(cfg):
     return f_fwd, f_bwd, f_iter
 
 
+def build_report(kernel_name):
+    """How the library that ran was built (csrc/build_info.json, written by _lib.build_library): scheduler flags, the code-generation check's
+    verdict, and registers / LDS / scratch / spills of the launched kernel.  A library of another origin (NMPC_LIB_PATH) reports that."""
+    from mpc_trajectory_generator_amd import _lib
+    if os.environ.get("NMPC_LIB_PATH"):
+        return {"library": os.environ["NMPC_LIB_PATH"], "note": "not the shipped build"}
+    info = _lib.build_info()
+    short = kernel_name.split("<")[0]
+    tmpl = kernel_name.split("<")[1].rstrip(">") if "<" in kernel_name else ""
+    res = {k: v for k, v in info.get("resources", {}).items() if short in k and (not tmpl or tmpl in k or tmpl.isdigit())}
+    chk = info.get("codegen_check", {})
+    return {"flags": " ".join(info.get("flags") or []), "source_hash": info.get("source_hash"), "stale": bool(info.get("stale")),
+            "codegen_check": {k: chk.get(k) for k in ("ok", "sched_changed", "sched_latent", "exec_hits", "exec_restores")},
+            "kernel_resources": next(iter(res.values()), None), "dynamic_lds_note": "LDS is dynamic: one slice per wave, DESIGN.md section 3"}
+
+
 def pmc_traffic(kernel_name, config, B, routes):
     """HBM bytes per launch from the rocprofv3 PMC passes, looked up in profiles/*/traffic.json by kernel
     name + hash of the kernel sources + workload: a figure measured on another version of the kernels
@@ -423,6 +439,7 @@ def main():
                    "batch_per_gpu": B, "n_u": cfg.n_u, "n_p": cfg.n_p, "parallelism": f"instance-sharded x{world}",
                    "gather": "one RCCL all_gather of u|y|status per step" if use_dist else "none (single GPU)"},
         "solver_variant": solver.variant,
+        "build": build_report(solver.kernel_name),
         "mean_inner_iters": stats[0] / stats[3], "mean_outer_iters": stats[1] / stats[3],
         "converged_frac": stats[2] / stats[3],
         # the headline counts every solve, converged or not (a non-converged solve still returns the controls the

@@ -1106,6 +1106,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             s.penalty = pen_c;
             s.cost = last_cost;
             s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - t_start) * 1e-5;
+            if (a.dbg) {       // experiments (NMPC_DEBUG_PRIO, scripts/slot_probe.py): start and finish on the 100 MHz clock, workgroup and wave
+                s.delta_y_norm_over_c = (double)t_start; s.cost = (double)(long long)__builtin_amdgcn_s_memrealtime();
+                s.f2_norm = (double)(blockIdx.x * TEAM_WAVES + wid);
+            }
 #ifdef NMPC2_TICKS
             s.last_problem_norm_fpr = (double)tk[4]; s.delta_y_norm_over_c = (double)tk[0]; s.f2_norm = (double)tk[1]; s.penalty = (double)tk[2]; s.cost = (double)tk[3];
 #endif

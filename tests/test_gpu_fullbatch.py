@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 B = 8192
 
 
-def bench_batch(name, seed=0):
+def bench_batch(name, seed=0, B=B):
     from mpc_trajectory_generator_amd.frontend import random_routes
     cfg = named_config(name)
     routes = random_routes(cfg, 11, 32, seed=1000 + seed)
@@ -23,13 +23,16 @@ def bench_batch(name, seed=0):
     return cfg, P
 
 
-@pytest.mark.parametrize("name,kernel,sample", [("cfg1", "nmpc_solve_hyb_kernel<ShapeDefault>", 64),
-                                                ("cfg2", "nmpc_solve_hyb2_kernel<ShapeN40>", 24),
-                                                ("cfg3", "nmpc_solve_hyb_kernel<ShapeNobs50>", 48),
-                                                ("cfg4", "nmpc_solve_hyb_kernel<ShapeDefault>", 48)])
-def test_full_batch_properties_and_sampled_parity(name, kernel, sample):
+@pytest.mark.parametrize("name,kernel,sample,B", [("cfg1", "nmpc_solve_hyb_kernel<ShapeDefault>", 64, 8192),
+                                                  ("cfg2", "nmpc_solve_hyb2_kernel<ShapeN40>", 24, 8192),
+                                                  ("cfg3", "nmpc_solve_hyb_kernel<ShapeNobs50>", 48, 8192),
+                                                  ("cfg4", "nmpc_solve_hyb_kernel<ShapeDefault>", 48, 8192),
+                                                  # BASELINE config 3 at its STATED total batch (65 536 over 8 GPUs; here on one): 8 waves of work per slot
+                                                  ("cfg3", "nmpc_solve_hyb_kernel<ShapeNobs50>", 48, 65536)],
+                         ids=["cfg1", "cfg2", "cfg3", "cfg4", "cfg3-65536"])
+def test_full_batch_properties_and_sampled_parity(name, kernel, sample, B):
     from mpc_trajectory_generator_amd.solver import BatchSolver
-    cfg, P = bench_batch(name)
+    cfg, P = bench_batch(name, B=B)
     s = BatchSolver(cfg, max_batch=B)
     try:
         assert s.kernel_name == kernel
