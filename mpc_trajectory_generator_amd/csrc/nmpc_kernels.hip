@@ -34,6 +34,9 @@ constexpr int TEAM_WAVES = 4;
 constexpr int TEAM_REQ_DOUBLES = 3 * 24 * 2;
 constexpr int TEAM_AREA_DOUBLES = 3 * 24 * 2 + 8;     // + psi[3], envelope[3]
 constexpr int TEAM_CTL_INTS = 64;
+// instances waiting for a wave (nmpc_solve_hyb.h): long = an outer criterion is still open after the outer iteration just finished, cold = all hold: the next outer iteration is the last (and short)
+constexpr int NPOOLS = 2;
+enum { POOL_LONG = 0, POOL_COLD = 1 };
 
 // PANOC constants
 constexpr double GAMMA_L_COEFF = 0.95;
@@ -84,7 +87,11 @@ struct KArgs {
     int park_depth;            // ... unless this many parked instances are already waiting for a favoured wave
     double *park;              // [B][park_stride]: parked solver state
     int *pool;                 // [B]: parked instance ids in arrival order (-1: not yet published)
-    unsigned int *pool_ctr;    // [0] next index to pop, [1] next index to push
+    unsigned int *pool_ctr;    // per pool: [0] next index to pop, [1] next index to push; after the pools: [2 * NPOOLS] = instances alive that are known to be long
+    int pool_cap;              // slots per pool ring (>= B)
+    int sched_mode;            // 0: an instance stays on its wave (but for the slot migration); 1: step-aside scheduling at outer-iteration boundaries (nmpc_solve_hyb.h)
+    int sched_long_cap;        // long instances alive beyond this many time-share the waves
+    int sched_cold_cap;        // cold instances step aside once this many long instances are alive (a batch without long instances has nobody to make room for)
     int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
     int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
     int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
@@ -1150,6 +1157,8 @@ struct nmpc_handle {
     size_t team_lds;       // hybrid kernel: dynamic LDS bytes of one workgroup (four slices + control block)
     unsigned int *d_queue;
     int park_min, park_depth;  // hybrid kernel: migrate instances after this many passes (0 = never) / pool depth limit
+    int sched_mode;            // step-aside scheduling (NMPC_SCHED=0 switches it off); long instances time-share beyond sched_theta x resident waves (NMPC_SCHED_THETA)
+    double sched_theta, sched_cold;
     int team_owners_forced;    // experiments (NMPC_TEAM_OWNERS): waves per workgroup that take instances, 0 = automatic
     int team_help;             // experiments (NMPC_TEAM_HELP=0): helpers never asked
     double cull_radius;        // eval_psi CULL (NMPC_CULL_RADIUS)
@@ -1246,6 +1255,11 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->park_min = 500; h->park_depth = 8;
     if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // tuning knobs; 0 switches migration off
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
+    h->sched_mode = 1; h->sched_theta = 0.8;
+    if (const char *env = getenv("NMPC_SCHED")) h->sched_mode = atoi(env);
+    if (const char *env = getenv("NMPC_SCHED_THETA")) { const double v = atof(env); if (v > 0.0) h->sched_theta = v; }
+    h->sched_cold = 0.4;
+    if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
     h->team_owners_forced = 0;
     h->team_help = 1;
     // culling radius: what the input bounds let the robot travel in a horizon, plus a margin (any value is exact: an evaluation
@@ -1365,16 +1379,18 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
         hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
         a.order = h->d_order;
-        if (h->P == 20 && h->park_min > 0) {      // two waves per SIMD: long-runners migrate to the favoured one
+        if ((h->P == 20 && (h->park_min > 0 || h->sched_mode > 0)) || (h->P == 40 && h->sched_mode > 0)) {      // instances may leave their wave at outer-iteration boundaries
+            const size_t cap = (size_t)h->max_batch;      // ring buffers: an instance waits in at most one slot at a time
             if (!h->d_park) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_park, (size_t)h->max_batch * nmpc::park_stride(h->pb.N) * 8));
-                HIP_TRY(h, hipMalloc((void **)&h->d_pool, (size_t)h->max_batch * sizeof(int)));
-                HIP_TRY(h, hipMalloc((void **)&h->d_pool_ctr, 2 * sizeof(unsigned int)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_pool, nmpc::NPOOLS * cap * sizeof(int)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_pool_ctr, (2 * nmpc::NPOOLS + 2) * sizeof(unsigned int)));
             }
-            HIP_TRY(h, hipMemsetAsync(h->d_pool, 0xFF, (size_t)B * sizeof(int), s));
-            HIP_TRY(h, hipMemsetAsync(h->d_pool_ctr, 0, 2 * sizeof(unsigned int), s));
-            a.park_min = h->park_min; a.park_depth = h->park_depth;
-            a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr;
+            HIP_TRY(h, hipMemsetAsync(h->d_pool, 0xFF, nmpc::NPOOLS * cap * sizeof(int), s));
+            HIP_TRY(h, hipMemsetAsync(h->d_pool_ctr, 0, (2 * nmpc::NPOOLS + 2) * sizeof(unsigned int), s));
+            a.park_min = h->P == 20 ? h->park_min : 0; a.park_depth = h->park_depth;      // (the slot migration is the one-stage kernel's: two waves per SIMD)
+            a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr; a.pool_cap = (int)cap;
+            a.sched_mode = h->sched_mode;
         }
     }
 #ifdef NMPC_PROFILE
@@ -1393,6 +1409,8 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         int wgs = (grid + owners - 1) / owners;
         if (wgs > max_wgs) wgs = max_wgs;
         a.team_owners = owners;
+        a.sched_long_cap = (int)(h->sched_theta * (double)(wgs * owners));
+        a.sched_cold_cap = (int)(h->sched_cold * (double)(wgs * owners));
         a.team_help = h->team_help;
         a.cull_radius = h->cull_radius;
 #ifdef NMPC_PROFILE

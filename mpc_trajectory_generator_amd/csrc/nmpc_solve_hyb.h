@@ -81,25 +81,38 @@ __device__ __forceinline__ double point_scalar(double v, int k)
 
 // parked-instance pool: one lane calls these.  Entries are published with release semantics at agent scope and
 // read with acquire semantics (other XCDs' L2s are not coherent with ours: plain loads could see stale lines)
-__device__ __forceinline__ int pool_pop(const KArgs &a)
+// Each pool is a ring of pool_cap >= B slots (an instance waits in at most one slot at a time; -1 = empty): positions are handed out by the two
+// counters, a pusher waits for its slot's previous tenant to have been taken (never long: fewer than pool_cap instances wait at any time).
+__device__ __forceinline__ int pool_pop(const KArgs &a, int c)
 {
+    unsigned int *ctr = a.pool_ctr + 2 * c;
     for (;;) {
-        const unsigned hd = __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned tl = __hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned hd = __hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tl = __hip_atomic_load(&ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (hd >= tl) return -1;
         unsigned expect = hd;
-        if (__hip_atomic_compare_exchange_strong(&a.pool_ctr[0], &expect, hd + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+        if (__hip_atomic_compare_exchange_strong(&ctr[0], &expect, hd + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT)) {
+            int *slot = a.pool + (size_t)c * a.pool_cap + hd % (unsigned)a.pool_cap;
             int inst;
-            do { inst = __hip_atomic_load(&a.pool[hd], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (inst < 0);
+            do { inst = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (inst < 0);
+            __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return inst;
         }
     }
 }
-__device__ __forceinline__ void pool_push(const KArgs &a, int inst)
+__device__ __forceinline__ void pool_push(const KArgs &a, int c, int inst)
 {
-    const unsigned slot = __hip_atomic_fetch_add(&a.pool_ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&a.pool[slot], inst, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // publishes the parked state too
+    const unsigned pos = __hip_atomic_fetch_add(&a.pool_ctr[2 * c + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int *slot = a.pool + (size_t)c * a.pool_cap + pos % (unsigned)a.pool_cap;
+    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) __builtin_amdgcn_s_sleep(1);
+    __hip_atomic_store(slot, inst, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // publishes the parked state too
+}
+// instances waiting in pool c (racy snapshot: a hint for the scheduling decisions, never for correctness)
+__device__ __forceinline__ int pool_depth(const KArgs &a, int c)
+{
+    return (int)(__hip_atomic_load(&a.pool_ctr[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                 __hip_atomic_load(&a.pool_ctr[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 template <class SH>
@@ -191,11 +204,15 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
         if (lane == 0) {
-            if (a.park_min > 0 && !unfavoured) { fetched = pool_pop(a); from_pool = fetched >= 0; }
+            const bool pools = a.park_min > 0 || a.sched_mode > 0;
+            if (pools && !unfavoured) { fetched = pool_pop(a, POOL_LONG); from_pool = fetched >= 0; }      // favoured waves: waiting long-runners first
             if (fetched < 0) {
                 const unsigned nxt = atomicAdd(a.queue, 1u);
                 if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
-                else if (a.park_min > 0) { fetched = pool_pop(a); from_pool = fetched >= 0; }
+                else if (pools) {
+                    for (int c = 0; c < NPOOLS && fetched < 0; ++c) fetched = pool_pop(a, c);
+                    from_pool = fetched >= 0;
+                }
             }
         }
         const int inst = __builtin_amdgcn_readfirstlane(fetched);
@@ -267,6 +284,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
         bool parked = false;
+        int park_cls = POOL_LONG;
+        bool long_counted = false;                 // this instance is in the count of long instances alive (KArgs.pool_ctr[2 NPOOLS])
         if (resumed) {                            // parked scalars
             const double *pks = a.park + (size_t)inst * PS + 6 * N;
             pen_c = pks[0];
@@ -275,6 +294,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             pk_last_fpr = pks[6]; pk_last_cost = pks[7];
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
             Lpar[13] = pks[13]; Lpar[14] = pks[14] + 1.0;
+            long_counted = pks[15] != 0.0;
         }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
@@ -712,14 +732,51 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
                     else if (timed_out) { final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; running = false; nu--; }      // (the report adds the one back)
-                    else if (a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min &&
-                             __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.B &&
-                             __builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(&a.pool_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                                                                  __hip_atomic_load(&a.pool_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) < a.park_depth) {
-                        // a long-runner on the unfavoured wave slot, favoured waves will still come back for work
-                        // and few instances are waiting for them already: hand it over at this outer-iteration boundary
-                        parked = true; running = false;
-                    } else f_start = true;
+                    else {
+                        // ---- an outer-iteration boundary: does this instance keep its wave?
+                        // What the iteration just finished revealed splits the batch exactly where it matters: COLD = every outer criterion holds
+                        // already, the next outer iteration is the last one, and short (two thirds of the headline batch, median 370 passes);
+                        // LONG = a criterion is still open (median 2 800 - 4 600 passes, up to 10 000).  A batch ends when its last instance does and
+                        // the waves are busy 70-80 % of that time (scripts/utilisation.py): long instances queue up behind each other on some waves
+                        // while others have run out of work.  So (1) a cold instance steps aside while anything else waits for a wave -- fresh
+                        // instances show early what they are -- and (2) once more long instances are alive than `sched_long_cap` (a fraction of the
+                        // waves), long instances TIME-SHARE: each gives up its wave after every outer iteration while others wait, so that they all
+                        // advance together instead of two of them taking turns on one wave (config 4: 111 -> 103 ms; configs 1 and 3: +-1 %).
+                        // Only WHERE and WHEN an instance runs changes; its arithmetic, hence every bit of the result, does not (tests: permutation
+                        // invariance, repeated solves, parity with the oracle on every path).
+                        bool yield_ = false;
+                        if (a.sched_mode > 0 || a.park_min > 0) {
+                            int dec = 0;
+                            if (lane == 0) {
+                                const bool fresh_left = (int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.B;
+                                int cls = POOL_LONG, y = 0;
+                                if (a.sched_mode > 0) {
+                                    const bool long_now = !(crit2 && pk_dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
+                                    cls = long_now ? POOL_LONG : POOL_COLD;
+                                    unsigned int *n_long = a.pool_ctr + 2 * NPOOLS;
+                                    if (long_now != long_counted) __hip_atomic_fetch_add(n_long, long_now ? 1u : ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    const bool long_wait = pool_depth(a, POOL_LONG) > 0;
+                                    const int alive = (int)__hip_atomic_load(n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    // (a cold instance only steps aside in a batch that HAS long instances to make room for, sched_cold_cap of them; a warm-started
+                                    // closed-loop step has next to none, and parking its many tiny instances would cost 5 %)
+                                    if (cls == POOL_COLD) y = (fresh_left || long_wait) && alive >= a.sched_cold_cap;
+                                    else y = (fresh_left || long_wait) && alive >= a.sched_long_cap;
+                                    dec = (long_now ? 2 : 0);
+                                }
+                                // a long-runner on the unfavoured wave slot while favoured waves will still come back for work: hand it over
+                                if (!y && a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min && fresh_left && pool_depth(a, POOL_LONG) < a.park_depth) {
+                                    y = 1; cls = POOL_LONG;
+                                }
+                                dec |= y | (cls << 2);
+                            }
+                            dec = __builtin_amdgcn_readfirstlane(dec);
+                            yield_ = (dec & 1) != 0;
+                            if (a.sched_mode > 0) long_counted = (dec & 2) != 0;
+                            park_cls = dec >> 2;
+                        }
+                        if (yield_) { parked = true; running = false; }
+                        else f_start = true;
+                    }
                 }
             }
 #ifdef NMPC_PROFILE
@@ -742,11 +799,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 ps_[0] = pen_c; ps_[1] = pk_eps_nu; ps_[2] = pk_dy_norm; ps_[3] = pk_f2_norm; ps_[4] = pk_dy_norm_plus;
                 ps_[5] = pk_f2_norm_plus; ps_[6] = pk_last_fpr; ps_[7] = pk_last_cost; ps_[8] = (double)nu;
                 ps_[9] = (double)inner_total; ps_[10] = (double)n_cost; ps_[11] = (double)n_grad; ps_[12] = (double)n_pass;
-                ps_[13] = Lpar[13]; ps_[14] = Lpar[14];
+                ps_[13] = Lpar[13]; ps_[14] = Lpar[14]; ps_[15] = long_counted ? 1.0 : 0.0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) pool_push(a, inst);
+            if (lane == 0) pool_push(a, park_cls, inst);
             if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
             NMPC_WAVE_SYNC();
             continue;
@@ -757,6 +814,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             uo[2 * t] = uv; uo[2 * t + 1] = uw;
             if (a.y_out) { const dbl2 yp_ = *Lyp; a.y_out[(size_t)inst * a.n1 + t] = yp_.x; a.y_out[(size_t)inst * a.n1 + N + t] = yp_.y; }
         }
+        if (lane == 0 && long_counted) __hip_atomic_fetch_add(a.pool_ctr + 2 * NPOOLS, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0 && a.st) {
             nmpc_status s;
             s.exit_status = final_status;

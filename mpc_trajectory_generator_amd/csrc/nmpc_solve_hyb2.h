@@ -56,17 +56,21 @@ __device__ __forceinline__ D2 next2(D2 v, int lane) { return D2{v.b, from_next<2
 // ---- state layout (stage pair j at lane j of both 32-lane halves)
 __device__ __forceinline__ double hdot2(D2 av, D2 aw, D2 bv, D2 bw) { return fma(av.a, bv.a, aw.a * bw.a) + fma(av.b, bv.b, aw.b * bw.b); }
 
-// a (v, w) x two-stage vector entry in LDS: 32 bytes {v_a, w_a, v_b, w_b}
-__device__ __forceinline__ void ld4(const lds_double2 *e, D2 &v, D2 &w)
+// A (v, w) x two-stage vector in LDS: CNT entries of four doubles, kept as TWO planes of 16-byte pairs -- plane 0: {v_a, w_a} of every entry,
+// plane 1: {v_b, w_b} -- so that the lanes of a ds_read_b128 / ds_write_b128 are 16 bytes apart (as one 32-byte record per entry they were 32 bytes
+// apart: lanes i and i + 4 of every eight hit the same banks, a two-way conflict on every access of the ring, the parked columns and the point /
+// gradient / request areas; round 3's "address-bit swizzle" against it cost more in address arithmetic than it saved -- the planes cost nothing:
+// the second access is the first one's address with another immediate offset).  `blk` is the vector's base, `e` the entry.
+template <int CNT> __device__ __forceinline__ void ld4(const lds_double2 *blk, int e, D2 &v, D2 &w)
 {
-    const dbl2 c0 = e[0], c1 = e[1];
+    const dbl2 c0 = blk[e], c1 = blk[CNT + e];
     v = D2{c0.x, c1.x};
     w = D2{c0.y, c1.y};
 }
-__device__ __forceinline__ void st4(lds_double2 *e, D2 v, D2 w)
+template <int CNT> __device__ __forceinline__ void st4(lds_double2 *blk, int e, D2 v, D2 w)
 {
-    e[0] = dbl2{v.a, w.a};
-    e[1] = dbl2{v.b, w.b};
+    blk[e] = dbl2{v.a, w.a};
+    blk[CNT + e] = dbl2{v.b, w.b};
 }
 
 // LDS slice of one wave (offsets in doubles); every per-stage table has room for 24 lane pairs = 48 stages
@@ -563,7 +567,7 @@ __device__ __forceinline__ double fbe_value2(double cost, double gamma, D2 sv, D
 #define NMPC2_LOAD_GRAD(BASE, OV, OW)                                          \
     do {                                                                       \
         D2 fv_, fw_;                                                           \
-        ld4((BASE) + 2 * tz, fv_, fw_);                                        \
+        ld4<H2_ENT>((BASE), tz, fv_, fw_);                                        \
         OV = D2{ina ? fv_.a : 0.0, inb ? fv_.b : 0.0};                         \
         OW = D2{ina ? fw_.a : 0.0, inb ? fw_.b : 0.0};                         \
     } while (0)
@@ -593,11 +597,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
     lds_double2 *LY = (lds_double2 *)(L + mp.Y);
     lds_double *Lrho = L + mp.rho;
     lds_double2 *V = (lds_double2 *)(L + mp.vec);
-    lds_double2 *Los = V + 2 * (0 * H2_COLS + t), *Log = V + 2 * (1 * H2_COLS + t), *Lq = V + 2 * (2 * H2_COLS + t);
-    lds_double2 *Lyp = V + 2 * (3 * H2_COLS + t), *Lgk = V + 2 * (6 * H2_COLS + t);
-    lds_double2 *LypE = V + 2 * (3 * H2_COLS + te), *Ly = V + 2 * (4 * H2_COLS + te);      // the same columns, by evaluation lane
+    // parked columns (bases; the entry is t in the state layout, te in the evaluation layout)
+    lds_double2 *Cos = V + 2 * H2_COLS * 0, *Cog = V + 2 * H2_COLS * 1, *Cq = V + 2 * H2_COLS * 2, *Cyp = V + 2 * H2_COLS * 3, *Cy = V + 2 * H2_COLS * 4,
+                *Cgk = V + 2 * H2_COLS * 6;
     lds_double2 *Pts = (lds_double2 *)(L + mp.pts), *Grd = (lds_double2 *)(L + mp.grd), *Lreq = (lds_double2 *)(L + mp.req);
-    if (lane < m) { st4(LS + 2 * (lane * H2_NS + H2_NS - 1), d2s(0.0), d2s(0.0)); st4(LY + 2 * (lane * H2_NS + H2_NS - 1), d2s(0.0), d2s(0.0)); }
+    if (lane < m) { st4<H2_NS>(LS + 2 * H2_NS * (lane), H2_NS - 1, d2s(0.0), d2s(0.0)); st4<H2_NS>(LY + 2 * H2_NS * (lane), H2_NS - 1, d2s(0.0), d2s(0.0)); }
     if (threadIdx.x < TEAM_CTL_INTS) ctl[threadIdx.x] = threadIdx.x == CTL_OWNERS ? a.team_owners : 0;
     __syncthreads();
     unsigned team_seq = 0;
@@ -607,29 +611,42 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
     lds_double *Lpar = L + mp.par;
 
     for (; wid < a.team_owners;) {
-        int fetched = -1;
+        // next instance: a fresh one from the queue; when that is empty, one that stepped aside at an outer-iteration boundary (long ones first)
+        int fetched = -1, from_pool = 0;
         if (lane == 0) {
             const unsigned nxt = atomicAdd(a.queue, 1u);
             if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
+            else if (a.sched_mode > 0) {
+                for (int c = 0; c < NPOOLS && fetched < 0; ++c) fetched = pool_pop(a, c);
+                from_pool = fetched >= 0;
+            }
         }
         const int inst = __builtin_amdgcn_readfirstlane(fetched);
+        const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
         if (inst < 0) break;
-        const long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
+        long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
         if (lane == 0) Lpar[19] = -1.0;                      // (nmpc_solve_hyb.h: the id is away while the tables change)
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
         WinState ws[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // this lane's cross-track windows
         if (lane == 0) Lpar[19] = (double)inst;              // (helpers tell by it whether their windows are still this instance's)
 
-        const double *u0 = a.u + (size_t)inst * a.n_u;
+        // a fresh instance starts from the caller's u0 / y0, a resumed one from its parked state (acquired by pool_pop): u | y | previous gradient
+        // in the layout of the caller's arrays, then 16 scalars (park_stride)
+        const double *pk = a.park + (size_t)inst * park_stride(N);
+        const double *u0 = resumed ? pk : a.u + (size_t)inst * a.n_u;
         D2 uv = D2{ina ? u0[4 * t] : 0.0, inb ? u0[4 * t + 2] : 0.0}, uw = D2{ina ? u0[4 * t + 1] : 0.0, inb ? u0[4 * t + 3] : 0.0};
         {
-            const double *yb = a.y0 ? a.y0 + (size_t)inst * a.n1 : nullptr;
+            const double *yb = resumed ? pk + 2 * N : (a.y0 ? a.y0 + (size_t)inst * a.n1 : nullptr);
             const D2 yv0 = D2{(yb && rea) ? yb[2 * te] : 0.0, (yb && reb) ? yb[2 * te + 1] : 0.0};
             const D2 yw0 = D2{(yb && rea) ? yb[N + 2 * te] : 0.0, (yb && reb) ? yb[N + 2 * te + 1] : 0.0};
-            st4(LypE, yv0, yw0);
-            st4(Ly, yv0, yw0);
+            st4<H2_COLS>(Cyp, te, yv0, yw0);
+            st4<H2_COLS>(Cy, te, yv0, yw0);
         }
-        st4(Lq, d2s(0.0), d2s(0.0));              // gradient_u_previous (AKKT residual): zero at the start of a solve
+        {   // gradient_u_previous (AKKT residual): zero at the start of a solve, carried across its inner solves
+            const double *qb = pk + 4 * N;
+            const bool ld = resumed && ina;
+            st4<H2_COLS>(Cq, t, D2{ld ? qb[4 * t] : 0.0, (ld && inb) ? qb[4 * t + 2] : 0.0}, D2{ld ? qb[4 * t + 1] : 0.0, (ld && inb) ? qb[4 * t + 3] : 0.0});
+        }
         D2 gv = d2s(0.0), gw = d2s(0.0), hv = d2s(0.0), hw = d2s(0.0), rv = d2s(0.0), rw = d2s(0.0), dv = d2s(0.0), dw = d2s(0.0);
         D2 pv = d2s(0.0), pw = d2s(0.0);          // line-search trial point being consumed
         D2 xv = d2s(0.0), xw = d2s(0.0);          // query point X of THIS half (-> evaluation points 0 and 1)
@@ -654,6 +671,15 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
         bool posted = false;
+        bool parked = false, long_counted = false;      // (nmpc_solve_hyb.h: stepping aside at outer-iteration boundaries)
+        int park_cls = POOL_LONG;
+        if (resumed) {
+            const double *pks = pk + 6 * N;
+            pen_c = pks[0]; cbar_inv = 1.0 / fmax(pen_c, 1.0);
+            eps_nu = pks[1]; dy_norm = pks[2]; f2_norm = pks[3]; dy_norm_plus = pks[4]; f2_norm_plus = pks[5]; last_fpr = pks[6]; last_cost = pks[7];
+            nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
+            t_start = (long long)pks[13]; long_counted = pks[15] != 0.0;
+        }
 #ifdef NMPC2_TICKS      // scripts/hyb2_sections.py: s_memtime ticks per section of a pass (fenced: upper bounds), reported in the status reals
         long long tk[5] = {0, 0, 0, 0, 0}, tkl = __builtin_amdgcn_s_memtime();
 #define NMPC2_TK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); tk[((i) + 4) % 5] += t_ - tkl; tkl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -695,7 +721,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             if (f_fb) {
                 f_fb = false;
                 tau = 0.0;
-                ld4(Lgk, gv, gw);
+                ld4<H2_COLS>(Cgk, t, gv, gw);
                 NMPC2_HALF_STEP(uv, uw);
                 xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
             }
@@ -721,7 +747,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     if (a.op.akkt_gradient == 2) exit_now = true;
                     else {
                         D2 q1, q2;
-                        ld4(Lq, q1, q2);
+                        ld4<H2_COLS>(Cq, t, q1, q2);
                         const bool top = a.op.akkt_gradient == 1;
                         const D2 b1 = top ? (iteration >= 1 ? d2s(0.0) : gv) : gv - q1;
                         const D2 b2 = top ? (iteration >= 1 ? d2s(0.0) : gw) : gw - q2;
@@ -742,8 +768,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         n_first = false; n_take_old = true;
                     } else {
                         D2 o1, o2, g1, g2;
-                        ld4(Los, o1, o2);
-                        ld4(Log, g1, g2);
+                        ld4<H2_COLS>(Cos, t, o1, o2);
+                        ld4<H2_COLS>(Cog, t, g1, g2);
                         const D2 s1 = uv - o1, s2 = uw - o2, y1 = rv - g1, y2 = rw - g2;
                         double ys, ss;
                         pair_sum(hdot2(s1, s2, y1, y2), hdot2(s1, s2, s1, s2), lane, ys, ss);
@@ -752,7 +778,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         if (__any(ok)) {
                             n_take_old = true;
                             n_head = lb_head == 0 ? m - 1 : lb_head - 1;
-                            if (in && h == 0) { st4(LS + 2 * (n_head * H2_NS + t), s1, s2); st4(LY + 2 * (n_head * H2_NS + t), y1, y2); }
+                            if (in && h == 0) { st4<H2_NS>(LS + 2 * H2_NS * (n_head), t, s1, s2); st4<H2_NS>(LY + 2 * H2_NS * (n_head), t, y1, y2); }
                             if (lane == 0) Lrho[n_head] = 1.0 / ys;
                             n_H0 = ys / group_sum<P>(hdot2(y1, y2, y1, y2), lane);
                             if (n_active < m) n_active++;
@@ -768,8 +794,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         for (int k = 0; k < MAXMEM; ++k) {
                             int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
                             D2 s1_, s2_, y1_, y2_;
-                            ld4(LS + 2 * (slot * H2_NS + tt), s1_, s2_);
-                            ld4(LY + 2 * (slot * H2_NS + tt), y1_, y2_);
+                            ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, s1_, s2_);
+                            ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, y1_, y2_);
                             const double al = Lrho[slot] * group_sum<P>(hdot2(s1_, s2_, dv, dw), lane);
                             alpha[k] = al;
                             dv = fma2(-al, y1_, dv); dw = fma2(-al, y2_, dw);
@@ -779,8 +805,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         for (int k = MAXMEM - 1; k >= 0; --k) {
                             int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
                             D2 s1_, s2_, y1_, y2_;
-                            ld4(LS + 2 * (slot * H2_NS + tt), s1_, s2_);
-                            ld4(LY + 2 * (slot * H2_NS + tt), y1_, y2_);
+                            ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, s1_, s2_);
+                            ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, y1_, y2_);
                             const double be = Lrho[slot] * group_sum<P>(hdot2(y1_, y2_, dv, dw), lane);
                             const double ab = alpha[k] - be;
                             dv = fma2(ab, s1_, dv); dw = fma2(ab, s2_, dw);
@@ -789,8 +815,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         double alpha[MAXMEM];
                         int slot = n_head;
                         D2 sc1, sc2, yc1, yc2;
-                        ld4(LS + 2 * (slot * H2_NS + tt), sc1, sc2);
-                        ld4(LY + 2 * (slot * H2_NS + tt), yc1, yc2);
+                        ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, sc1, sc2);
+                        ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, yc1, yc2);
                         double rc_ = Lrho[slot];
 #pragma unroll
                         for (int k = 0; k < MAXMEM; ++k) {
@@ -800,8 +826,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                                 double rn_ = 0.0;
                                 if (k + 1 < n_active) {
                                     slot = slot + 1 == m ? 0 : slot + 1;
-                                    ld4(LS + 2 * (slot * H2_NS + tt), sn1, sn2);
-                                    ld4(LY + 2 * (slot * H2_NS + tt), yn1, yn2);
+                                    ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, sn1, sn2);
+                                    ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, yn1, yn2);
                                     rn_ = Lrho[slot];
                                 }
                                 const double al = rc_ * group_sum<P>(hdot2(sc1, sc2, dv, dw), lane);
@@ -818,8 +844,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                                 double rn_ = 0.0;
                                 if (k > 0) {
                                     slot = slot == 0 ? m - 1 : slot - 1;
-                                    ld4(LS + 2 * (slot * H2_NS + tt), sn1, sn2);
-                                    ld4(LY + 2 * (slot * H2_NS + tt), yn1, yn2);
+                                    ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, sn1, sn2);
+                                    ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, yn1, yn2);
                                     rn_ = Lrho[slot];
                                 }
                                 const double be = rc_ * group_sum<P>(hdot2(yc1, yc2, dv, dw), lane);
@@ -840,9 +866,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     // team: idle waves of this workgroup evaluate the trials tau = 2^-2 .. 2^-10 of this direction meanwhile
                     if (a.team_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
                         if (t < H2_ENT && h == 0) {
-                            st4(Lreq + 2 * t, uv, uw);
-                            st4(Lreq + 2 * (H2_ENT + t), rv, rw);
-                            st4(Lreq + 2 * (2 * H2_ENT + t), dv, dw);
+                            st4<H2_ENT>(Lreq, t, uv, uw);
+                            st4<H2_ENT>(Lreq + 2 * H2_ENT * 1, t, rv, rw);
+                            st4<H2_ENT>(Lreq + 2 * H2_ENT * (2), t, dv, dw);
                         }
                         if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; Lpar[17] = gamma; }
                         team_seq = team_seq >= 0xffff0u ? 1u : team_seq + 1u;
@@ -869,7 +895,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             // ---------------------------------------------------------------- start an inner solve
             if (f_start) {
                 f_start = false;
-                { D2 y1, y2; ld4(Ly, y1, y2); st4(Ly, clamp2(y1, -1e12, 1e12), clamp2(y2, -1e12, 1e12)); }      // y <- Pi_Y(y)
+                { D2 y1, y2; ld4<H2_COLS>(Cy, te, y1, y2); st4<H2_COLS>(Cy, te, clamp2(y1, -1e12, 1e12), clamp2(y2, -1e12, 1e12)); }      // y <- Pi_Y(y)
                 lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
                 const D2 h1 = D2{EPSILON_LIPSCHITZ * uv.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.a : DELTA_LIPSCHITZ,
                                  EPSILON_LIPSCHITZ * uv.b > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.b : DELTA_LIPSCHITZ};
@@ -890,17 +916,17 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             NMPC2_TK(0);
             // query points: state layout -> LDS -> evaluation layout (X of half 0 | X of half 1 | Y)
             if (t < H2_ENT) {
-                st4(Pts + 2 * (h * H2_ENT + t), xv, xw);
-                if (h == 0) st4(Pts + 2 * (2 * H2_ENT + t), yqv, yqw);
+                st4<H2_ENT>(Pts + 2 * H2_ENT * (h), t, xv, xw);
+                if (h == 0) st4<H2_ENT>(Pts + 2 * H2_ENT * (2), t, yqv, yqw);
             }
             NMPC_WAVE_SYNC();
             D2 zv, zw, yv, yw;
-            ld4(Pts + 2 * (q * H2_ENT + te), zv, zw);
-            ld4(Ly, yv, yw);
+            ld4<H2_ENT>(Pts + 2 * H2_ENT * (q), te, zv, zw);
+            ld4<H2_COLS>(Cy, te, yv, yw);
             NMPC2_TK(1);
             eval_psi2<SH, false, NMPC_WIN2>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ws);
             NMPC2_TK(2);
-            if (need_grad) st4(Grd + 2 * (q * H2_ENT + te), egv, egw);
+            if (need_grad) st4<H2_ENT>(Grd + 2 * H2_ENT * (q), te, egv, egw);
             NMPC_WAVE_SYNC();
             const double psiA = point_scalar(psi, 0), psiB = point_scalar(psi, 1), psiC = point_scalar(psi, 2);
             NMPC2_TK(3);
@@ -908,7 +934,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 #define NMPC2_TAKE_TRIAL_(PSI, FETCH)                                                  \
             do {                                                                       \
                 n_grad++;                                                              \
-                st4(Lq, gv, gw);                     /* cache_previous_gradient */     \
+                st4<H2_COLS>(Cq, t, gv, gw);                     /* cache_previous_gradient */     \
                 cost = (PSI);                                                          \
                 FETCH;                                                                 \
                 const double omt_ = 1.0 - tau;                                         \
@@ -945,7 +971,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     f_back = true;
                 } else {
                     if (state == D_LIP) {
-                        lb_first = false; st4(Los, uv, uw); st4(Log, rv, rw);
+                        lb_first = false; st4<H2_COLS>(Cos, t, uv, uw); st4<H2_COLS>(Cog, t, rv, rw);
                         if (iteration == 0) {
                             n_grad++;
                             uv = hv; uw = hw;
@@ -958,13 +984,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             dv = rv; dw = rw;                            // empty buffer: d = r
                             rhs_ls = NMPC2_FBE(uv, uw) - sigma * nr2;
                             tau = 1.0; ls_n = 0;
-                            if (a.op.ls_failure == 1) st4(Lgk, gv, gw);
+                            if (a.op.ls_failure == 1) st4<H2_COLS>(Cgk, t, gv, gw);
                             f_trials = true;
                         }
                     } else {
                         lb_first = n_first; lb_head = n_head; lb_active = n_active; H0 = n_H0;      // commit
-                        if (n_take_old) { st4(Los, uv, uw); st4(Log, rv, rw); }
-                        if (a.op.ls_failure == 1) st4(Lgk, gv, gw);
+                        if (n_take_old) { st4<H2_COLS>(Cos, t, uv, uw); st4<H2_COLS>(Cog, t, rv, rw); }
+                        if (a.op.ls_failure == 1) st4<H2_COLS>(Cgk, t, gv, gw);
                         NMPC2_TAKE_TRIAL(psiB, 1);                       // tau = 1
                         if (rejected) NMPC2_TAKE_TRIAL(psiC, 2);         // tau = 1/2
                         if (posted) {
@@ -1010,8 +1036,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                                     n_grad += (unsigned)jstop + 1u; ls_n += jstop;
                                     tau *= jstop == 0 ? 1.0 : (jstop == 1 ? 0.5 : 0.25);
                                     if (jstop > 0) prev_ag = ag + 2 * ((jstop - 1) * H2_ENT);
-                                    if (prev_ag) { D2 p1, p2; NMPC2_LOAD_GRAD(prev_ag, p1, p2); st4(Lq, p1, p2); }
-                                    else st4(Lq, gv, gw);
+                                    if (prev_ag) { D2 p1, p2; NMPC2_LOAD_GRAD(prev_ag, p1, p2); st4<H2_COLS>(Cq, t, p1, p2); }
+                                    else st4<H2_COLS>(Cq, t, gv, gw);
                                     cost = sc_[jstop];
                                     NMPC2_LOAD_GRAD(ag + 2 * (jstop * H2_ENT), gv, gw);
                                     const double omt_ = 1.0 - tau;
@@ -1053,7 +1079,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 const D2 cv = clamp2(tv, a.pb.amin, a.pb.amax), cw_ = clamp2(tw, -a.pb.awmax, a.pb.awmax);
                 const D2 ypv = D2{inea ? fma(pen_c, eav.a - cv.a, yv.a) : 0.0, ineb ? fma(pen_c, eav.b - cv.b, yv.b) : 0.0};
                 const D2 ypw = D2{inea ? fma(pen_c, eaw.a - cw_.a, yw.a) : 0.0, ineb ? fma(pen_c, eaw.b - cw_.b, yw.b) : 0.0};
-                st4(LypE, ypv, ypw);
+                st4<H2_COLS>(Cyp, te, ypv, ypw);
                 const D2 d1 = ypv - yv, d2_ = ypw - yw;
                 dy_norm_plus = sqrt(group_sum<20>((inea ? fma(d1.a, d1.a, d2_.a * d2_.a) : 0.0) + (ineb ? fma(d1.b, d1.b, d2_.b * d2_.b) : 0.0), lane));
                 dy_norm_plus = point_scalar(dy_norm_plus, 0);
@@ -1069,24 +1095,74 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                                                         f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
                     if (!stall) { pen_c *= a.op.penalty_update; cbar_inv = 1.0 / fmax(pen_c, 1.0); }
                     eps_nu = fmax(a.op.tolerance_update * eps_nu, a.op.tolerance);
-                    st4(Ly, ypv, ypw);
+                    st4<H2_COLS>(Cy, te, ypv, ypw);
                     dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
                     nu++;
                     if (nu == a.op.max_outer) { final_status = NMPC_NOT_CONVERGED_ITERATIONS; running = false; }
                     else if (timed_out) { final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; running = false; nu--; }
-                    else f_start = true;
+                    else {
+                        // an outer-iteration boundary: cold instances step aside while others wait, long ones time-share once they outnumber
+                        // the waves (the argument and the numbers: nmpc_solve_hyb.h; here there is no favoured wave slot, hence no migration)
+                        bool yield_ = false;
+                        if (a.sched_mode > 0) {
+                            int dec = 0;
+                            if (lane == 0) {
+                                const bool fresh_left = (int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.B;
+                                const bool long_now = !(crit2 && dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
+                                unsigned int *n_long = a.pool_ctr + 2 * NPOOLS;
+                                if (long_now != long_counted) __hip_atomic_fetch_add(n_long, long_now ? 1u : ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const bool long_wait = pool_depth(a, POOL_LONG) > 0;
+                                int y;
+                                const int alive = (int)__hip_atomic_load(n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (!long_now) y = (fresh_left || long_wait) && alive >= a.sched_cold_cap;
+                                else y = (fresh_left || long_wait) && alive >= a.sched_long_cap;
+                                dec = y | (long_now ? 2 : 0);
+                            }
+                            dec = __builtin_amdgcn_readfirstlane(dec);
+                            yield_ = (dec & 1) != 0; long_counted = (dec & 2) != 0; park_cls = long_counted ? POOL_LONG : POOL_COLD;
+                        }
+                        if (yield_) { parked = true; running = false; }
+                        else f_start = true;
+                    }
                 }
             }
         }
 
+        // ------------------------------------------------------------------ stepped aside: state out, into the pool
+        if (parked) {
+            double *po = a.park + (size_t)inst * park_stride(N);
+            NMPC_WAVE_SYNC();          // (the multipliers were stored by the evaluation lanes, the state lanes read them)
+            if (in && h == 0) {
+                D2 q1, q2;
+                ld4<H2_COLS>(Cq, t, q1, q2);
+                po[4 * t] = uv.a; po[4 * t + 1] = uw.a; po[4 * N + 4 * t] = q1.a; po[4 * N + 4 * t + 1] = q2.a;
+                if (inb) { po[4 * t + 2] = uv.b; po[4 * t + 3] = uw.b; po[4 * N + 4 * t + 2] = q1.b; po[4 * N + 4 * t + 3] = q2.b; }
+                D2 y1, y2;
+                ld4<H2_COLS>(Cy, t, y1, y2);
+                po[2 * N + 2 * t] = y1.a; po[3 * N + 2 * t] = y2.a;
+                if (inb) { po[2 * N + 2 * t + 1] = y1.b; po[3 * N + 2 * t + 1] = y2.b; }
+            }
+            if (lane == 0) {
+                double *ps_ = po + 6 * N;
+                ps_[0] = pen_c; ps_[1] = eps_nu; ps_[2] = dy_norm; ps_[3] = f2_norm; ps_[4] = dy_norm_plus; ps_[5] = f2_norm_plus; ps_[6] = last_fpr; ps_[7] = last_cost;
+                ps_[8] = (double)nu; ps_[9] = (double)inner_total; ps_[10] = (double)n_cost; ps_[11] = (double)n_grad; ps_[12] = (double)n_pass;
+                ps_[13] = (double)t_start; ps_[14] = 0.0; ps_[15] = long_counted ? 1.0 : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) pool_push(a, park_cls, inst);
+            NMPC_WAVE_SYNC();
+            continue;
+        }
         // ------------------------------------------------------------------ results
+        if (lane == 0 && long_counted) __hip_atomic_fetch_add(a.pool_ctr + 2 * NPOOLS, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (in && h == 0) {
             double *uo = a.u + (size_t)inst * a.n_u;
             uo[4 * t] = uv.a; uo[4 * t + 1] = uw.a;
             if (inb) { uo[4 * t + 2] = uv.b; uo[4 * t + 3] = uw.b; }
             if (a.y_out) {
                 D2 y1, y2;
-                ld4(Lyp, y1, y2);
+                ld4<H2_COLS>(Cyp, t, y1, y2);
                 double *yo = a.y_out + (size_t)inst * a.n1;
                 yo[2 * t] = y1.a; yo[N + 2 * t] = y2.a;
                 if (inb) { yo[2 * t + 1] = y1.b; yo[N + 2 * t + 1] = y2.b; }
@@ -1146,11 +1222,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         lds_double *Lw = (lds_double *)lds + w * slice;
         const lds_double2 *rq = (const lds_double2 *)(Lw + mp.req);
         D2 u1, u2, r1, r2, e1, e2, yv, yw;
-        ld4(rq + 2 * te, u1, u2);
-        ld4(rq + 2 * (H2_ENT + te), r1, r2);
-        ld4(rq + 2 * (2 * H2_ENT + te), e1, e2);
+        ld4<H2_ENT>(rq, te, u1, u2);
+        ld4<H2_ENT>(rq + 2 * H2_ENT * 1, te, r1, r2);
+        ld4<H2_ENT>(rq + 2 * H2_ENT * (2), te, e1, e2);
         const double c_w = Lw[mp.par + 15], cbar_w = Lw[mp.par + 16], gam_w = Lw[mp.par + 17];
-        ld4((const lds_double2 *)(Lw + mp.vec) + 2 * (4 * H2_COLS + te), yv, yw);
+        ld4<H2_COLS>((const lds_double2 *)(Lw + mp.vec) + 2 * H2_COLS * (4), te, yv, yw);
         const double tau_w = __hiloint2double((1023 - (2 + 3 * k + q)) << 20, 0), omt_w = 1.0 - tau_w;
         const D2 zv = fma2(-tau_w, e1, fma2(-omt_w, r1, u1)), zw = fma2(-tau_w, e2, fma2(-omt_w, r2, u2));
         double psi, pen;
@@ -1169,7 +1245,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         const double gg_ = group_sum<20>((inea ? fma(egv.a, egv.a, egw.a * egw.a) : 0.0) + (ineb ? fma(egv.b, egv.b, egw.b * egw.b) : 0.0), lane);
         const double lhs_ = psi - (0.5 * gam_w) * gg_ + (0.5 * dist2_) / gam_w;
         lds_double *ar = L + (w * 3 + k) * TEAM2_AREA_DOUBLES;
-        st4((lds_double2 *)ar + 2 * (q * H2_ENT + te), egv, egw);
+        st4<H2_ENT>((lds_double2 *)ar + 2 * H2_ENT * (q), te, egv, egw);
         if (te == 0) { ar[3 * H2_ENT * 4 + q] = psi; ar[3 * H2_ENT * 4 + 4 + q] = lhs_; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();

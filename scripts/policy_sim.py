@@ -46,3 +46,90 @@ e_ps, lls = park_short()
 print(json.dumps({"cfg": name, "us_per_pass": us, "slots": S, "work_ms": float(p.sum() * us * 1e-3 / S), "longest_ms": float(p.max() * us * 1e-3),
                   "shipped_ms": simple(order), "park_short_ms": e_ps, "park_short_last_long_start_ms": lls, "lpt_ms": simple(np.argsort(-p)),
                   "long_frac": float(long_.mean())}))
+
+
+# ---- round-robin variants at outer-iteration boundaries (quantum = one outer iteration; the remaining passes of an instance are spread evenly
+#      over its remaining outer iterations) ----
+def quanta(i):
+    n = int(z["outer"][i])
+    if n <= 1: return [p[i]]
+    return [min(p1[i], p[i])] + [rem[i] / (n - 1)] * (n - 1)
+
+def rr(policy):
+    """policy 'pure': one FIFO, every instance re-enqueued after each outer iteration.
+       policy 'classes': fresh first (discovery), then revealed-long instances (time-shared when they outnumber the waves), shorts fill in"""
+    from collections import deque
+    Q = {i: quanta(i) for i in range(B)}
+    fresh = deque(order); longq = deque(); shortq = deque()
+    h = [(0.0, k) for k in range(S)]; heapq.heapify(h); end = 0.0
+    run = {}          # wave -> (instance, next quantum index)
+    while h:
+        t, k = heapq.heappop(h)
+        job = run.pop(k, None)
+        if job is not None:
+            i, q = job
+            if q < len(Q[i]):
+                if policy == "pure":
+                    fresh.append((i, q))
+                else:
+                    if fresh: (longq if long_[i] else shortq).append((i, q))
+                    elif long_[i]:
+                        if longq: longq.append((i, q))
+                        else: run[k] = (i, q)          # a wave of its own: goes on
+                    else:
+                        if longq: shortq.append((i, q))
+                        else: run[k] = (i, q)
+            else:
+                end = max(end, t)
+        if k not in run:
+            nxt = None
+            if fresh:
+                x = fresh.popleft(); nxt = x if isinstance(x, tuple) else (x, 0)
+            elif longq: nxt = longq.popleft()
+            elif shortq: nxt = shortq.popleft()
+            if nxt is None: continue
+            run[k] = nxt
+            t += 0.008          # fetch / park + prepare_instance
+        i, q = run[k]
+        run[k] = (i, q + 1)
+        heapq.heappush(h, (t + Q[i][q] * us * 1e-3, k))
+    return end
+
+print(json.dumps({"cfg": name, "rr_pure_ms": rr("pure"), "rr_classes_ms": rr("classes")}))
+
+
+def v5(theta=1.0):
+    """fresh first; after its first outer iteration an instance is hot (||F2|| > delta), warm (only the multiplier criterion fails) or cold (will
+    finish in its next outer iteration).  cold / warm step aside while anything more urgent waits; hot instances go on unless they outnumber the
+    waves (then they time-share, one outer iteration at a time)."""
+    from collections import deque
+    hot_c = f2 > 1e-4; warm_c = (~hot_c) & (z["dy1"] > 1e-4)
+    Q = {i: quanta(i) for i in range(B)}
+    fresh = deque((i, 0) for i in order); pools = {"hot": deque(), "warm": deque(), "cold": deque()}
+    h = [(0.0, k) for k in range(S)]; heapq.heapify(h); end = 0.0; run = {}
+    n_hot_alive = 0; revealed = set()
+    while h:
+        t, k = heapq.heappop(h)
+        job = run.pop(k, None)
+        if job is not None:
+            i, q = job
+            if q >= len(Q[i]):
+                end = max(end, t)
+                if hot_c[i] and i in revealed: n_hot_alive -= 1
+            else:
+                cls = "hot" if hot_c[i] else ("warm" if warm_c[i] else "cold")
+                if cls == "hot" and i not in revealed: revealed.add(i); n_hot_alive += 1
+                if cls == "cold": y = bool(fresh or pools["hot"] or pools["warm"])
+                elif cls == "warm": y = bool(fresh or pools["hot"])
+                else: y = n_hot_alive >= theta * S and bool(fresh or pools["hot"])
+                if y: pools[cls].append((i, q))
+                else: run[k] = (i, q)
+        if k not in run:
+            nxt = fresh.popleft() if fresh else next((pools[c].popleft() for c in ("hot", "warm", "cold") if pools[c]), None)
+            if nxt is None: continue
+            run[k] = nxt; t += 0.008
+        i, q = run[k]; run[k] = (i, q + 1)
+        heapq.heappush(h, (t + Q[i][q] * us * 1e-3, k))
+    return end
+
+print(json.dumps({"cfg": name, "v5_theta0.9_ms": v5(0.9), "v5_theta0.75_ms": v5(0.75), "v5_theta0.5_ms": v5(0.5), "v5_no_rr_ms": v5(1e9)}))
