@@ -671,6 +671,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
         bool posted = false;
+        bool akkt_last = false;                         // the last step's residual was below the tolerance: the AKKT residual will be needed again
         bool parked = false, long_counted = false;      // (nmpc_solve_hyb.h: stepping aside at outer-iteration boundaries)
         int park_cls = POOL_LONG;
         if (resumed) {
@@ -740,19 +741,42 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             if (f_begin) {
                 f_begin = false;
                 rv = uv - hv; rw = uw - hw;
-                pair_sum(hdot2(rv, rw, rv, rw), hdot2(gv, gw, rv, rw), lane, nr2, gr);
+                // The reductions at the head of a step -- ||r||^2 | <g, r>, the curvature pair's <s, y> | <s, s>, the AKKT residual | <y, y> -- do not
+                // depend on each other; issued together their trees overlap (each is a chain of six dependent levels and this wave has its SIMD to
+                // itself).  What the step will need is predicted, wave-uniformly: the curvature pair unless the buffer has just been reset, the
+                // AKKT residual if the last step needed it.  The values are the ones the sequential code would form (same operands, same trees);
+                // whatever was not predicted is formed below as before.
+                const bool spec_lb = iteration >= 1 && !lb_first;
+                const bool spec_akkt = akkt_last && a.op.akkt_gradient == 1 && iteration >= 1;
+                D2 s1 = d2s(0.0), s2 = d2s(0.0), y1 = d2s(0.0), y2 = d2s(0.0), a1 = d2s(0.0), a2 = d2s(0.0);
+                double ys = 0.0, ss = 0.0, yy = 0.0, akkt2 = 0.0;
+                if (spec_akkt) { a1 = D2{rv.a / gamma, rv.b / gamma}; a2 = D2{rw.a / gamma, rw.b / gamma}; }
+                if (spec_lb) {
+                    D2 o1, o2, g1, g2;
+                    ld4<H2_COLS>(Cos, t, o1, o2);
+                    ld4<H2_COLS>(Cog, t, g1, g2);
+                    s1 = uv - o1; s2 = uw - o2; y1 = rv - g1; y2 = rw - g2;
+                    pair_sum(hdot2(rv, rw, rv, rw), hdot2(gv, gw, rv, rw), lane, nr2, gr);
+                    pair_sum(hdot2(s1, s2, y1, y2), hdot2(s1, s2, s1, s2), lane, ys, ss);
+                    pair_sum(hdot2(a1, a2, a1, a2), hdot2(y1, y2, y1, y2), lane, akkt2, yy);
+                } else {
+                    pair_sum(hdot2(rv, rw, rv, rw), hdot2(gv, gw, rv, rw), lane, nr2, gr);
+                    if (spec_akkt) akkt2 = group_sum<P>(hdot2(a1, a2, a1, a2), lane);
+                }
                 norm_r = sqrt(nr2);
                 bool exit_now = false;
-                if (__any(norm_r < a.op.tolerance)) {
+                akkt_last = __any(norm_r < a.op.tolerance);
+                if (akkt_last) {
                     if (a.op.akkt_gradient == 2) exit_now = true;
+                    else if (spec_akkt) exit_now = __any(sqrt(akkt2) < eps_nu);
                     else {
                         D2 q1, q2;
                         ld4<H2_COLS>(Cq, t, q1, q2);
                         const bool top = a.op.akkt_gradient == 1;
                         const D2 b1 = top ? (iteration >= 1 ? d2s(0.0) : gv) : gv - q1;
                         const D2 b2 = top ? (iteration >= 1 ? d2s(0.0) : gw) : gw - q2;
-                        const D2 a1 = D2{rv.a / gamma + b1.a, rv.b / gamma + b1.b}, a2 = D2{rw.a / gamma + b2.a, rw.b / gamma + b2.b};
-                        exit_now = __any(sqrt(group_sum<P>(hdot2(a1, a2, a1, a2), lane)) < eps_nu);
+                        const D2 c1 = D2{rv.a / gamma + b1.a, rv.b / gamma + b1.b}, c2 = D2{rw.a / gamma + b2.a, rw.b / gamma + b2.b};
+                        exit_now = __any(sqrt(group_sum<P>(hdot2(c1, c2, c1, c2), lane)) < eps_nu);
                     }
                 }
                 if (exit_now) {
@@ -767,12 +791,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     if (lb_first) {
                         n_first = false; n_take_old = true;
                     } else {
-                        D2 o1, o2, g1, g2;
-                        ld4<H2_COLS>(Cos, t, o1, o2);
-                        ld4<H2_COLS>(Cog, t, g1, g2);
-                        const D2 s1 = uv - o1, s2 = uw - o2, y1 = rv - g1, y2 = rw - g2;
-                        double ys, ss;
-                        pair_sum(hdot2(s1, s2, y1, y2), hdot2(s1, s2, s1, s2), lane, ys, ss);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
                         if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
                         if (__any(ok)) {
@@ -780,7 +798,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             n_head = lb_head == 0 ? m - 1 : lb_head - 1;
                             if (in && h == 0) { st4<H2_NS>(LS + 2 * H2_NS * (n_head), t, s1, s2); st4<H2_NS>(LY + 2 * H2_NS * (n_head), t, y1, y2); }
                             if (lane == 0) Lrho[n_head] = 1.0 / ys;
-                            n_H0 = ys / group_sum<P>(hdot2(y1, y2, y1, y2), lane);
+                            n_H0 = ys / yy;
                             if (n_active < m) n_active++;
                             NMPC_WAVE_SYNC();
                         }

@@ -1,10 +1,12 @@
 """How much of a batch's wave-slot time is idle, and is the batch bounded by its longest instance?  Start / finish of every instance on the
-100 MHz clock (NMPC_DEBUG_PRIO: 2 for the one-stage kernel, 1 for the two-stage one).  usage: python scripts/utilisation.py cfgN [seed]"""
+100 MHz clock (NMPC_DEBUG_PRIO: 2 for the one-stage kernel, 1 for the two-stage one), with the step-aside scheduling OFF: the diagnosis that led to it
+(round 4: 71 / 82 / 77 / 82 % busy for configs 1-4; bounds max(work, longest instance) = 42 / 141 / 85 / 94 ms against 48 / 173 / 99 / 114 measured).  usage: python scripts/utilisation.py cfgN [seed]"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, ".")
 name = sys.argv[1]; seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 os.environ["NMPC_DEBUG_PRIO"] = "1" if name == "cfg2" else "2"
+os.environ.setdefault("NMPC_SCHED", "0")      # an instance's start -> finish time is busy time only while instances keep their waves
 from mpc_trajectory_generator_amd import named_config
 from mpc_trajectory_generator_amd.solver import BatchSolver
 from mpc_trajectory_generator_amd.harness import synthetic_batch
