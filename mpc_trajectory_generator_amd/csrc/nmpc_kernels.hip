@@ -87,7 +87,7 @@ struct KArgs {
     int park_depth;            // ... unless this many parked instances are already waiting for a favoured wave
     double *park;              // [B][park_stride]: parked solver state
     int *pool;                 // [B]: parked instance ids in arrival order (-1: not yet published)
-    unsigned int *pool_ctr;    // per pool: [0] next index to pop, [1] next index to push; after the pools: [2 * NPOOLS] = instances alive that are known to be long
+    unsigned int *pool_ctr;    // per pool: head, tail, count, pad (nmpc_solve_hyb.h: POOL_CTRS); after the pools: instances alive that are known to be long
     int pool_cap;              // slots per pool ring (>= B)
     int sched_mode;            // 0: an instance stays on its wave (but for the slot migration); 1: step-aside scheduling at outer-iteration boundaries (nmpc_solve_hyb.h)
     int sched_long_cap;        // long instances alive beyond this many time-share the waves
@@ -1384,10 +1384,10 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
             if (!h->d_park) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_park, (size_t)h->max_batch * nmpc::park_stride(h->pb.N) * 8));
                 HIP_TRY(h, hipMalloc((void **)&h->d_pool, nmpc::NPOOLS * cap * sizeof(int)));
-                HIP_TRY(h, hipMalloc((void **)&h->d_pool_ctr, (2 * nmpc::NPOOLS + 2) * sizeof(unsigned int)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_pool_ctr, (4 * nmpc::NPOOLS + 2) * sizeof(unsigned int)));
             }
             HIP_TRY(h, hipMemsetAsync(h->d_pool, 0xFF, nmpc::NPOOLS * cap * sizeof(int), s));
-            HIP_TRY(h, hipMemsetAsync(h->d_pool_ctr, 0, (2 * nmpc::NPOOLS + 2) * sizeof(unsigned int), s));
+            HIP_TRY(h, hipMemsetAsync(h->d_pool_ctr, 0, (4 * nmpc::NPOOLS + 2) * sizeof(unsigned int), s));
             a.park_min = h->P == 20 ? h->park_min : 0; a.park_depth = h->park_depth;      // (the slot migration is the one-stage kernel's: two waves per SIMD)
             a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr; a.pool_cap = (int)cap;
             a.sched_mode = h->sched_mode;

@@ -81,38 +81,41 @@ __device__ __forceinline__ double point_scalar(double v, int k)
 
 // parked-instance pool: one lane calls these.  Entries are published with release semantics at agent scope and
 // read with acquire semantics (other XCDs' L2s are not coherent with ours: plain loads could see stale lines)
-// Each pool is a ring of pool_cap >= B slots (an instance waits in at most one slot at a time; -1 = empty): positions are handed out by the two
-// counters, a pusher waits for its slot's previous tenant to have been taken (never long: fewer than pool_cap instances wait at any time).
+// Each pool is a ring of pool_cap >= B slots (an instance waits in at most one slot at a time; -1 = empty) with three counters: positions
+// handed to poppers (head) and to pushers (tail), and the number of published entries nobody has claimed yet (count).  Every operation is a
+// fetch-add -- NO compare-and-swap loops: with two thousand waves on one counter a CAS loop collapses (measured at B = 32 768: 33 attempts per
+// pop, 75 us each, the waves 65 % of their time in here).  A popper first takes one unit of `count` (giving it back if there was none), which
+// entitles it to the next head position; the pusher of that position may still be about to publish it -- a few hundred nanoseconds.
+constexpr int POOL_CTRS = 4;       // head | tail | count | (pad) per pool; after the pools: instances alive that are known to be long
 __device__ __forceinline__ int pool_pop(const KArgs &a, int c)
 {
-    unsigned int *ctr = a.pool_ctr + 2 * c;
-    for (;;) {
-        const unsigned hd = __hip_atomic_load(&ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned tl = __hip_atomic_load(&ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (hd >= tl) return -1;
-        unsigned expect = hd;
-        if (__hip_atomic_compare_exchange_strong(&ctr[0], &expect, hd + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)) {
-            int *slot = a.pool + (size_t)c * a.pool_cap + hd % (unsigned)a.pool_cap;
-            int inst;
-            do { inst = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (inst < 0);
-            __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return inst;
-        }
+    unsigned int *ctr = a.pool_ctr + POOL_CTRS * c;
+    int *cnt = (int *)(ctr + 2);
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) return -1;
+    if (__hip_atomic_fetch_add(cnt, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) {
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
     }
+    const unsigned pos = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int *slot = a.pool + (size_t)c * a.pool_cap + pos % (unsigned)a.pool_cap;
+    int inst;
+    do { inst = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (inst < 0);
+    __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return inst;
 }
 __device__ __forceinline__ void pool_push(const KArgs &a, int c, int inst)
 {
-    const unsigned pos = __hip_atomic_fetch_add(&a.pool_ctr[2 * c + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int *ctr = a.pool_ctr + POOL_CTRS * c;
+    const unsigned pos = __hip_atomic_fetch_add(&ctr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int *slot = a.pool + (size_t)c * a.pool_cap + pos % (unsigned)a.pool_cap;
-    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) __builtin_amdgcn_s_sleep(1);      // (the previous lap's tenant: taken long ago)
     __hip_atomic_store(slot, inst, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // publishes the parked state too
+    __hip_atomic_fetch_add((int *)(ctr + 2), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-// instances waiting in pool c (racy snapshot: a hint for the scheduling decisions, never for correctness)
+// instances waiting in pool c (a snapshot: a hint for the scheduling decisions, never for correctness)
 __device__ __forceinline__ int pool_depth(const KArgs &a, int c)
 {
-    return (int)(__hip_atomic_load(&a.pool_ctr[2 * c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                 __hip_atomic_load(&a.pool_ctr[2 * c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return __hip_atomic_load((int *)(a.pool_ctr + POOL_CTRS * c + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <class SH>
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                 if (a.sched_mode > 0) {
                                     const bool long_now = !(crit2 && pk_dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
                                     cls = long_now ? POOL_LONG : POOL_COLD;
-                                    unsigned int *n_long = a.pool_ctr + 2 * NPOOLS;
+                                    unsigned int *n_long = a.pool_ctr + POOL_CTRS * NPOOLS;
                                     if (long_now != long_counted) __hip_atomic_fetch_add(n_long, long_now ? 1u : ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     const bool long_wait = pool_depth(a, POOL_LONG) > 0;
                                     const int alive = (int)__hip_atomic_load(n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             uo[2 * t] = uv; uo[2 * t + 1] = uw;
             if (a.y_out) { const dbl2 yp_ = *Lyp; a.y_out[(size_t)inst * a.n1 + t] = yp_.x; a.y_out[(size_t)inst * a.n1 + N + t] = yp_.y; }
         }
-        if (lane == 0 && long_counted) __hip_atomic_fetch_add(a.pool_ctr + 2 * NPOOLS, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && long_counted) __hip_atomic_fetch_add(a.pool_ctr + POOL_CTRS * NPOOLS, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0 && a.st) {
             nmpc_status s;
             s.exit_status = final_status;

@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             if (lane == 0) {
                                 const bool fresh_left = (int)__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.B;
                                 const bool long_now = !(crit2 && dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL);
-                                unsigned int *n_long = a.pool_ctr + 2 * NPOOLS;
+                                unsigned int *n_long = a.pool_ctr + POOL_CTRS * NPOOLS;
                                 if (long_now != long_counted) __hip_atomic_fetch_add(n_long, long_now ? 1u : ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 const bool long_wait = pool_depth(a, POOL_LONG) > 0;
                                 int y;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             continue;
         }
         // ------------------------------------------------------------------ results
-        if (lane == 0 && long_counted) __hip_atomic_fetch_add(a.pool_ctr + 2 * NPOOLS, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && long_counted) __hip_atomic_fetch_add(a.pool_ctr + POOL_CTRS * NPOOLS, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (in && h == 0) {
             double *uo = a.u + (size_t)inst * a.n_u;
             uo[4 * t] = uv.a; uo[4 * t + 1] = uw.a;
