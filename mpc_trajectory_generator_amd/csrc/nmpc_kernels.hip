@@ -1255,7 +1255,9 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->park_min = 500; h->park_depth = 8;
     if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // tuning knobs; 0 switches migration off
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
-    h->sched_mode = 1; h->sched_theta = 0.8;
+    // long instances time-share beyond this fraction of the resident waves: the favoured half of them for the one-stage kernel (two waves per SIMD),
+    // 0.8 for the two-stage kernel (one wave per SIMD); measured flat between 0.4 and 0.7 / 0.5 and 1.0 (profiles/r04/sched_sweep*.txt)
+    h->sched_mode = 1; h->sched_theta = h->P == 20 ? 0.5 : 0.8;
     if (const char *env = getenv("NMPC_SCHED")) h->sched_mode = atoi(env);
     if (const char *env = getenv("NMPC_SCHED_THETA")) { const double v = atof(env); if (v > 0.0) h->sched_theta = v; }
     h->sched_cold = 0.4;
