@@ -288,6 +288,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
         bool parked = false;
         int park_cls = POOL_LONG;
+        unsigned q_pass = 0;                      // n_pass at the last outer-iteration boundary (or at the start of this leg)
         bool long_counted = false;                 // this instance is in the count of long instances alive (KArgs.pool_ctr[2 NPOOLS])
         if (resumed) {                            // parked scalars
             const double *pks = a.park + (size_t)inst * PS + 6 * N;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             pk_last_fpr = pks[6]; pk_last_cost = pks[7];
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
             Lpar[13] = pks[13]; Lpar[14] = pks[14] + 1.0;
-            long_counted = pks[15] != 0.0;
+            long_counted = pks[15] != 0.0; q_pass = n_pass;
         }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
@@ -762,8 +763,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                     const int alive = (int)__hip_atomic_load(n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     // (a cold instance only steps aside in a batch that HAS long instances to make room for, sched_cold_cap of them; a warm-started
                                     // closed-loop step has next to none, and parking its many tiny instances would cost 5 %)
-                                    if (cls == POOL_COLD) y = (fresh_left || long_wait) && alive >= a.sched_cold_cap;
-                                    else y = (fresh_left || long_wait) && alive >= a.sched_long_cap;
+                                    if (cls == POOL_COLD) y = (fresh_left || long_wait) && alive >= a.sched_cold_cap && n_pass >= 150u;      // (short solves: parking costs more than it gains)
+                                    else y = (fresh_left || long_wait) && alive >= a.sched_long_cap && n_pass - q_pass >= 150u;      // (an outer iteration of a few passes is not worth a hand-over)
                                     dec = (long_now ? 2 : 0);
                                 }
                                 // a long-runner on the unfavoured wave slot while favoured waves will still come back for work: hand it over
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                             if (a.sched_mode > 0) long_counted = (dec & 2) != 0;
                             park_cls = dec >> 2;
                         }
+                        q_pass = n_pass;
                         if (yield_) { parked = true; running = false; }
                         else f_start = true;
                     }

@@ -672,6 +672,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         bool running = true, timed_out = false;
         bool posted = false;
         bool akkt_last = false;                         // the last step's residual was below the tolerance: the AKKT residual will be needed again
+        unsigned q_pass = 0;                            // n_pass at the last outer-iteration boundary (or at the start of this leg)
         bool parked = false, long_counted = false;      // (nmpc_solve_hyb.h: stepping aside at outer-iteration boundaries)
         int park_cls = POOL_LONG;
         if (resumed) {
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             pen_c = pks[0]; cbar_inv = 1.0 / fmax(pen_c, 1.0);
             eps_nu = pks[1]; dy_norm = pks[2]; f2_norm = pks[3]; dy_norm_plus = pks[4]; f2_norm_plus = pks[5]; last_fpr = pks[6]; last_cost = pks[7];
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
-            t_start = (long long)pks[13]; long_counted = pks[15] != 0.0;
+            t_start = (long long)pks[13]; long_counted = pks[15] != 0.0; q_pass = n_pass;
         }
 #ifdef NMPC2_TICKS      // scripts/hyb2_sections.py: s_memtime ticks per section of a pass (fenced: upper bounds), reported in the status reals
         long long tk[5] = {0, 0, 0, 0, 0}, tkl = __builtin_amdgcn_s_memtime();
@@ -1132,13 +1133,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                                 const bool long_wait = pool_depth(a, POOL_LONG) > 0;
                                 int y;
                                 const int alive = (int)__hip_atomic_load(n_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (!long_now) y = (fresh_left || long_wait) && alive >= a.sched_cold_cap;
-                                else y = (fresh_left || long_wait) && alive >= a.sched_long_cap;
+                                if (!long_now) y = (fresh_left || long_wait) && alive >= a.sched_cold_cap && n_pass >= 150u;
+                                else y = (fresh_left || long_wait) && alive >= a.sched_long_cap && n_pass - q_pass >= 150u;
                                 dec = y | (long_now ? 2 : 0);
                             }
                             dec = __builtin_amdgcn_readfirstlane(dec);
                             yield_ = (dec & 1) != 0; long_counted = (dec & 2) != 0; park_cls = long_counted ? POOL_LONG : POOL_COLD;
                         }
+                        q_pass = n_pass;
                         if (yield_) { parked = true; running = false; }
                         else f_start = true;
                     }
