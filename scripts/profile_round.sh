@@ -36,4 +36,8 @@ python scripts/perf_probe.py $TAG > "$OUT/perf_probe.json" 2> "$OUT/perf_probe.l
 for c in cfg1 cfg3 cfg4; do python scripts/seeds_unseen.py $c > "$OUT/seeds_unseen_$c.json" 2> "$OUT/seeds_unseen_$c.log"; done
 for c in cfg1 cfg2; do python scripts/latency_team.py $c > "$OUT/latency_team_$c.json" 2> "$OUT/latency_team_$c.log"; done
 rocprofv3 --pmc $SQ1 -d "$OUT/pmc_cfg2_sq" -o pmc --output-format csv -- python scripts/pmc_cfg2.py > "$OUT/pmc_cfg2_sq.log" 2>&1
+for c in cfg1 cfg2 cfg3 cfg4; do python scripts/sched_ab.py $c "NMPC_SCHED=0" "NMPC_SCHED=1"; done > "$OUT/sched_ab.jsonl" 2> "$OUT/sched_ab.log"      # the step-aside scheduling off / on, seeds 0-2
+for c in cfg1 cfg2 cfg3 cfg4; do python scripts/utilisation.py $c 0; done > "$OUT/utilisation.jsonl" 2> "$OUT/utilisation.log"      # busy wave-slot time without it
+python scripts/call_latency.py > "$OUT/call_latency.txt" 2>&1
+python scripts/scrub_probe.py shipped cfg1 cfg2 cfg3 cfg4 > "$OUT/scrub_probe.jsonl" 2>&1
 python scripts/profile_summarise.py "$OUT"

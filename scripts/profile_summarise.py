@@ -56,7 +56,7 @@ for k in fetch:
                         "routes": 32, "fetch_size_kib": fetch[k], "write_size_kib": write[k],
                         "hbm_bytes_per_launch": 2 * fetch[k] * 1024 + write[k] * 1024,
                         "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of scripts/pmc_one.py (two launches of the "
-                               "headline batch); FETCH_SIZE doubled per the gfx950 wide-read correction, WRITE_SIZE as reported"})
+                               "headline batch); FETCH_SIZE x 2 and WRITE_SIZE x 1: calibrated on this kernel's own 8 B/lane access width, profiles/r04/fetch_calibration.json"})
 with open(os.path.join(out, "traffic.json"), "w") as fh:
     json.dump(entries, fh, indent=1)
 print(json.dumps(entries))
