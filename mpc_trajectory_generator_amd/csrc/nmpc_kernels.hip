@@ -1166,6 +1166,7 @@ struct nmpc_handle {
     int *d_pool;
     unsigned int *d_pool_ctr;
     int *d_order;              // launch order (hard-looking instances first)
+    bool use_order;
     unsigned char *d_cls;
     // staging buffers of the host path
     double *d_p, *d_u, *d_y0, *d_c0, *d_yout, *d_psi, *d_grad, *d_F1, *d_F2;
@@ -1269,6 +1270,8 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->cull_radius = 1.1 * pb->N * pb->ts * fmax(fabs(pb->vmin), fabs(pb->vmax));
     if (const char *env = getenv("NMPC_CULL_RADIUS")) { const double v = atof(env); if (v > 0.0) h->cull_radius = v; }
     if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
+    h->use_order = true;
+    if (const char *env = getenv("NMPC_ORDER")) h->use_order = atoi(env) != 0;      // experiments: 0 = instances in index order (scripts/sched_ab.py)
     if (const char *env = getenv("NMPC_TEAM_OWNERS")) { const int v = atoi(env); if (v >= 1 && v <= nmpc::TEAM_WAVES) h->team_owners_forced = v; }
     h->d_order = nullptr;
     h->d_cls = nullptr;
@@ -1378,9 +1381,11 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     // 20 < N_hor <= 32 two (dual kernel), longer horizons one, with the whole wave as one group
     const int grid = B < h->grid_cap ? B : h->grid_cap;          // waves that take instances
     if (B > grid) {        // more instances than resident waves: hand the hard-looking ones out first
-        hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
-        hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
-        a.order = h->d_order;
+        if (h->use_order) {
+            hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
+            hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
+            a.order = h->d_order;
+        }
         if ((h->P == 20 && (h->park_min > 0 || h->sched_mode > 0)) || (h->P == 40 && h->sched_mode > 0)) {      // instances may leave their wave at outer-iteration boundaries
             const size_t cap = (size_t)h->max_batch;      // ring buffers: an instance waits in at most one slot at a time
             if (!h->d_park) {
