@@ -23,7 +23,10 @@
  *
  * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success
  * or a negative nmpc_error, never throws; buffers are caller-allocated; a handle is not
- * thread-safe, distinct handles are.  Data layout (all IEEE f64, row-major):
+ * thread-safe, distinct handles are.  A handle owns device scratch (work queue, launch order, the pools
+ * instances wait in between outer iterations): its asynchronous calls must be ordered on ONE stream
+ * at a time; two batches in flight take two handles (bench.py's `pipelined` leg).
+ * Data layout (all IEEE f64, row-major):
  *   p  [B][n_p]   parameter vectors, layout of reference src/path_generator.py:378-379
  *   u  [B][n_u]   decision vectors (v_0, w_0, v_1, w_1, ...)   src/mpc/mpc_generator.py:83,157-158
  *   y  [B][n1]    ALM multipliers of F1 = [acc ; omega_acc]    src/mpc/mpc_generator.py:162

@@ -14,7 +14,7 @@ flags of the real build plus machine-code dumps and checks
    change from run to run.  Found with tests/scrub + scripts/scrub_bisect.py.)
 
 `build_library()` (_lib.py) calls verify() after every real compilation and refuses the library if either check fails.
-CLI:  python -m mpc_trajectory_generator_amd.codegen_check [hipcc flags ...]     (default: the Makefile's flags)"""
+CLI:  python -m mpc_trajectory_generator_amd.codegen_check [--src file.hip] [hipcc flags ...]     (default: the library's source, the Makefile's flags)"""
 import os
 import re
 import subprocess
@@ -210,10 +210,11 @@ def kernel_resources(asm_text):
     return out
 
 
-def verify(flags=None):
-    """-> dict(ok, flags, kernels, sched_changed, sched_latent, exec_hits, details, resources).  Two extra compilations side by side (about 25 s)."""
+def verify(flags=None, src=None):
+    """-> dict(ok, flags, kernels, sched_changed, sched_latent, exec_hits, details, resources).  Two extra compilations side by side (about 25 s).
+    `src`: another source file than the library's (the minimal cases under tests/repro/)."""
     flags = makefile_flags() if flags is None else list(flags)
-    src = os.path.join(CSRC, "nmpc_kernels.hip")
+    src = src or os.path.join(CSRC, "nmpc_kernels.hip")
     with tempfile.TemporaryDirectory() as td:
         cmds = [[HIPCC] + BASE + flags + ["-mllvm", "-print-before=machine-scheduler", "-mllvm", "-print-after=machine-scheduler", "-o", os.path.join(td, "x.s"), src],
                 [HIPCC] + BASE + flags + ["-mllvm", "-print-after=virtregrewriter", "-o", os.path.join(td, "y.s"), src]]
@@ -243,7 +244,10 @@ def verify(flags=None):
 
 
 def main():
-    res = verify(sys.argv[1:] or None)
+    argv, src = sys.argv[1:], None
+    if "--src" in argv:
+        i = argv.index("--src"); src = argv[i + 1]; argv = argv[:i] + argv[i + 2:]
+    res = verify(argv or None, src)
     print({k: v for k, v in res.items() if k not in ("details", "resources")})
     for d in res.get("details", []):
         print("  " + d[:400])
