@@ -241,6 +241,14 @@ def test_migration_between_wave_slots_is_invisible(monkeypatch):
     finally:
         s.close()
     assert np.array_equal(off[0], gpu[0]) and np.array_equal(off[2]["reserved"], gpu[2]["reserved"])
+    monkeypatch.setenv("NMPC_ORDER", "0")                         # ... and in index order instead of the launch order, scheduler off as well
+    monkeypatch.setenv("NMPC_SCHED", "0")
+    s = BatchSolver(cfg, max_batch=2600)
+    try:
+        plain = s.solve(P)
+    finally:
+        s.close()
+    assert np.array_equal(plain[0], gpu[0]) and np.array_equal(plain[1], gpu[1]) and np.array_equal(plain[2]["reserved"], gpu[2]["reserved"])
 
 
 def test_solve_warm_start_multipliers_penalty(solvers):
