@@ -1,0 +1,50 @@
+"""The build gate of DESIGN.md section 5.9 (mpc_trajectory_generator_amd/codegen_check.py) against the machine code that made it necessary:
+two excerpts of LLVM MIR dumps of this project's own earlier sources (tests/golden/mir_*.txt, a dozen instructions each) -- the minimal
+cases of the two compiler defects -- and their repaired counterparts.  CPU only, no compilation."""
+import os
+import re
+
+from mpc_trajectory_generator_amd import codegen_check as cc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _read(name):
+    return open(os.path.join(GOLDEN, name)).read()
+
+
+def test_scheduler_check_flags_the_hoisted_lane_copy():
+    text = _read("mir_sched_permlane_swap.txt")
+    stats, bad, latent = cc.check_scheduler(text)
+    assert len(stats) == 1 and stats[0][2] == 7                       # one function, seven instructions
+    moved = [b for b in bad if "COPY %26673.sub3" in b[2]]
+    assert moved, bad                                                  # the copy reads sub3 from another definition after scheduling
+    assert any("V_PERMLANE32_SWAP" in l[3] for l in latent), latent    # and the read-undef flag that permitted it is reported by itself
+
+
+def test_scheduler_check_accepts_an_order_preserving_schedule():
+    text = _read("mir_sched_permlane_swap.txt")
+    head, before, after = re.split(r"^# \*\*\* IR Dump (?:Before|After) Machine Instruction Scheduler \(machine-scheduler\) \*\*\*:\n", text, flags=re.M)
+    # without the wrong flag on the swap's tied def, and scheduled in the original order: nothing to report
+    clean = before.replace("undef %26673.sub0:vreg_128_align2 = V_PERMLANE32_SWAP", "%26673.sub0:vreg_128_align2 = V_PERMLANE32_SWAP")
+    mk = lambda when, body: f"# *** IR Dump {when} Machine Instruction Scheduler (machine-scheduler) ***:\n" + body
+    stats, bad, latent = cc.check_scheduler(mk("Before", clean) + mk("After", clean))
+    assert len(stats) == 1 and not bad and not latent
+    # the flag alone (no instruction moved yet) is already a finding: any scheduler may use it
+    stats, bad, latent = cc.check_scheduler(mk("Before", before) + mk("After", before))
+    assert not bad and latent
+
+
+def test_exec_restore_check_flags_vector_copies_in_front_of_the_restore():
+    text = _read("mir_exec_restore_copies.txt")
+    nfun, nrestore, hits = cc.check_exec_restores(text)
+    assert nfun == 1 and nrestore == 1
+    assert [h[2].split(" = ")[0].split()[-1] for h in hits] == ["$agpr106_agpr107", "$agpr92_agpr93", "$agpr48_agpr49"]
+    # the same block with the copies behind the restore (where the allocator belongs) passes; the SGPR copy in front of it is fine
+    lines = text.split("\n")
+    copies = [l for l in lines if re.search(r"\$agpr\d+_agpr\d+ = COPY", l)]
+    rest = [l for l in lines if l not in copies]
+    k = next(i for i, l in enumerate(rest) if "S_OR_B64 $exec" in l)
+    fixed = "\n".join(rest[:k + 1] + copies + rest[k + 1:])
+    nfun, nrestore, hits = cc.check_exec_restores(fixed)
+    assert nrestore == 1 and not hits
