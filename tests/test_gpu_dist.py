@@ -107,3 +107,18 @@ def test_solve_sharded_over_rccl_world1():
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _SHARDED], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """The whole N = 2 path of bench.py with two real processes -- spawn, rank-dependent batches, shard bookkeeping, the gather and its check,
+    max-over-ranks timing, the per-rank report -- on a box with one GPU: both ranks on device 0, the collective over gloo (RCCL refuses two
+    ranks on one device).  A functional check; the line says so (`shared_gpu`) and its value is not a measurement."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1024", "--no-extras"], {"NMPC_BENCH_SHARED_GPU": "1"})
+    assert r.returncode == 0, (r.stderr + r.stdout)[-2500:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["shared_gpu"] is True and out["gather_checked"] is True
+    assert "functional check" in out["config"]["gather"] and out["config"]["batch_per_gpu"] == 1024
+    assert [r_["rank"] for r_ in out["ranks"]] == [0, 1]
+    assert out["ranks"][0]["shard"] == [0, 1024] and out["ranks"][1]["shard"] == [1024, 2048]
+    assert all(r_["kernel_ms"] > 0 for r_ in out["ranks"]) and out["value"] > 0
