@@ -26,6 +26,7 @@ namespace nmpc {
 constexpr int NZ = 20;         // reference configs/default.yaml:35
 constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
 constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
+constexpr int GRAM_NST = 20;   // stages the Gram-form L-BFGS of the hybrid kernel runs over (N_hor <= 20, zero padded)
 constexpr int SEG_STRIDE = 5;  // doubles per reference segment in LDS (odd: the per-lane window gathers of eval_psi spread over all banks)
 // team mode of the hybrid kernel (nmpc_solve_hyb.h): four waves per workgroup; a wave without work of its own evaluates
 // line-search trials for its siblings.  Request = u, r, d by stage (3 x 24 pairs); one result area = three trials'
@@ -64,6 +65,8 @@ struct LdsMap {
     int vec;     // 7 x P parked (v, w) pairs: L-BFGS old u / old r, previous gradient, y+, y, reference speed, grad at u_k
     int rho;     // m
     int S, Y;    // m slots x N lanes x (v, w)
+    int nv;      // hybrid kernel, Gram-form L-BFGS: the four vectors of an iteration -- s | y | r | g -- as 4 x GRAM_NST (v, w) pairs by stage
+    int gsy, gyy; // ... and the inner products it keeps, [slot][slot]: <s_a, y_b> (a older than b; zero otherwise), <y_a, y_b>
     int total;
 };
 
@@ -156,9 +159,10 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     mp.seg = o; o += SEG_STRIDE * (N + 5);
     mp.obs = o; o += 3 * (nobs + 4);
     const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
-    mp.f2 = o;  o += points * (nobs + ndyn + 1);
+    // (three-point layout: only the cost-layer kernel writes F2, and it has no parked vectors -- the array shares their place)
+    mp.f2 = o;  o += P == 20 ? 0 : points * (nobs + ndyn + 1);
     mp.rho = o; o += MAXMEM;
-    const int cols = P == 20 ? 32 : P;                // >= lay_cols; the hybrid kernel parks 32 state-layout columns
+    const int cols = P == 20 ? 24 : P;                // >= lay_cols (hybrid kernel: state lanes 24..31 share column 23 -- all zeros)
     // one point per wave keeps its solver vectors in registers and needs ellipse columns for the real stages only: without
     // the 64-column tables a 40-stage slice is 21.6 KB instead of 32.9 KB -- 7 resident waves per CU instead of 4
     mp.dyn_stride = P == 64 ? ((N + 1) & ~1) : (P == 20 ? 24 : P);
@@ -166,10 +170,16 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     o = (o + 1) & ~1;
     mp.req = o; o += P == 20 ? TEAM_REQ_DOUBLES : 0;
     mp.vec = o; o += P == 64 ? 0 : 7 * 2 * cols;
+    if (P == 20) { mp.f2 = mp.vec; if (7 * 2 * cols < points * (nobs + ndyn + 1)) o = mp.vec + points * (nobs + ndyn + 1); }
     o = (o + 1) & ~1;                                 // 16-byte alignment for the double2 arrays
-    const int ring = P == 20 ? N + 1 : N;             // (+1: the hybrid kernel keeps an all-zero column per slot)
+    // hybrid kernel: GRAM_NST + 1 columns per slot whatever N is -- the Gram batch reads a slot as GRAM_NST pairs, the last column is
+    // all zeros (lanes beyond the horizon read it); gsy | gyy | S | Y are contiguous (zeroed together when the buffer is reset)
+    mp.gsy = o; o += P == 20 ? MAXMEM * MAXMEM : 0;
+    mp.gyy = o; o += P == 20 ? MAXMEM * MAXMEM : 0;
+    const int ring = P == 20 ? GRAM_NST + 1 : N;
     mp.S = o;   o += 2 * ring * MAXMEM;
     mp.Y = o;   o += 2 * ring * MAXMEM;
+    mp.nv = o;  o += P == 20 ? 4 * 2 * GRAM_NST : 0;
     mp.total = (o + 1) & ~1;
     // team mode: a helper wave's slice holds one result area per (owner, task) from offset 0 -- twelve of them; short horizons make slices
     // smaller than that (N_hor <= 14), and an area past the slice would land in the next wave's tables

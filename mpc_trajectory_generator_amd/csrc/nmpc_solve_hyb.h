@@ -118,11 +118,72 @@ __device__ __forceinline__ int pool_depth(const KArgs &a, int c)
     return __hip_atomic_load((int *)(a.pool_ctr + POOL_CTRS * c + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- Gram-form L-BFGS (this kernel's; the oracle follows it for N_hor <= 20: oracle/nmpc_oracle.c, lbfgs_apply_gram) ----
+// The two-loop recursion chains twenty horizon reductions per iteration, each waiting for the one before.  Here the twenty inner
+// products it needs come from ONE batch of independent ones -- lane (c, q) of the wave runs the fma chain of quarter q (five stages)
+// of the products of ring pair c with the iteration's y and r, lanes c = 10..12 those among s, y, r, g themselves (which also gives
+// ||r||^2, <g, r>, <s, y>, <s, s>, <y, y>: no tree sums at the head of a step); two permlane swaps add the four quarters -- and the
+// products among the ring vectors are kept from the iteration each pair entered (gsy, gyy in LDS).  The coefficients alpha_j, beta_j
+// then follow from two short recurrences in lanes 0..9 of every row (the coefficient of step j reaches the row by DPP row_newbcast:j),
+// and the direction is updated with them as the two-loop recursion would.  Measured (scripts/ubench/mfma_f64.hip): v_mfma_f64_4x4x4
+// shares the f64 pipe with the vector ALU (17 cycles = 4 v_fma_f64) and is an exact ascending fma chain over k, but for this shape
+// it would compute four times the products the lanes need -- so the batch is plain v_fma_f64.
+template <int J>
+__device__ __forceinline__ double row_bcast_lane(double x)       // lane J of this lane's row (one v_mov_b64_dpp)
+{
+    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xF, 0xF, false);
+}
+// acc - x[lane J of the row] * y in ONE instruction (the recurrences' critical path); the two wait states a DPP read of a fresh VALU
+// result needs are spelled out, the compiler does not see into the statement
+template <int J>
+__device__ __forceinline__ double fnma_row_bcast(double acc, double x, double y)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+    return acc;
+}
+template <int J>
+__device__ __forceinline__ double fma_row_bcast(double acc, double x, double y)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+    return acc;
+}
+// the value lane `ln` (a constant) holds, as a wave-uniform scalar
+__device__ __forceinline__ double lane_scalar(double v, int ln)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), ln);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ln);
+    return __hiloint2double(hi, lo);
+}
+// one step of the first / second recurrence (J = age of the pair) with the direction's update of that step
+#define NMPC_GRAM_FWD(J)                                                                       \
+    do {                                                                                       \
+        const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J);        \
+        const double gs_ = Lgsy[pkrow + pj_], gy_ = Lgyy[pkrow + pj_];                         \
+        const dbl2 yp_ = LY[pj_ * NS + tt];                                                    \
+        const double al_ = rho_k * ga1;                                                        \
+        ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                                              \
+        const double bc_ = row_bcast_lane<(J)>(al_);                                           \
+        ga2 = fma(-bc_, gy_, ga2);                                                             \
+        dv = fma(-bc_, yp_.x, dv); dw = fma(-bc_, yp_.y, dw);                                  \
+    } while (0)
+#define NMPC_GRAM_BWD(J)                                                                       \
+    do {                                                                                       \
+        const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J);        \
+        const double gr_ = Lgsy[pj_ * MAXMEM + pk_];                                           \
+        const dbl2 sp_ = LS[pj_ * NS + tt];                                                    \
+        const double be_ = rho_k * ga2;                                                        \
+        const double ab_ = alv - be_;                                                          \
+        ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                                               \
+        const double bc_ = row_bcast_lane<(J)>(ab_);                                           \
+        dv = fma(bc_, sp_.x, dv); dw = fma(bc_, sp_.y, dw);                                    \
+    } while (0)
+
 template <class SH>
 __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArgs a)
 {
+    static_assert(MAXMEM == 10, "the Gram-form recurrences are written out for ten pairs");
     constexpr int PE = 20;                      // evaluation layout: three lane groups (nmpc_device.h)
-    constexpr int P = 32, COLS = 32;            // state layout: stage t at lane t of both 32-lane halves
+    constexpr int P = 32, COLS = 24;            // state layout: stage t at lane t of both 32-lane halves (lanes 24..31 share LDS column 23: zeros)
     extern __shared__ double lds[];
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave of the team
     const int slice = the_map<SH, PE>(a).total;
@@ -146,18 +207,28 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     const int src0 = in ? lay_lane<PE>(0, t) : lane, src1 = in ? lay_lane<PE>(1, t) : lane, src2 = in ? lay_lane<PE>(2, t) : lane;
     // state-layout lane that holds this evaluation lane's query point: X of half q (points 0, 1), Y (point 2)
     const int zsrcX = ine ? (q < 2 ? 32 * q + te : te) : lane, zsrcY = ine ? te : lane;
-    // L-BFGS ring: N + 1 columns per slot, the last one all zeros -- lanes beyond the horizon read it
-    const int NS = N + 1, tt = in ? t : N;
+    // L-BFGS ring: GRAM_NST + 1 columns per slot, the last one all zeros -- lanes beyond GRAM_NST read it (stages N.. are zeros too)
+    constexpr int NS = GRAM_NST + 1;
+    const int tt = t < GRAM_NST ? t : GRAM_NST;
     lds_double2 *LS = (lds_double2 *)(L + mp.S);
     lds_double2 *LY = (lds_double2 *)(L + mp.Y);
     lds_double *Lrho = L + mp.rho;
-    lds_double2 *Los = (lds_double2 *)(L + mp.vec) + t;      // parked pairs, one column per stage
+    lds_double2 *Lnv = (lds_double2 *)(L + mp.nv);            // Gram-form L-BFGS: s | y | r | g of the iteration, by stage
+    lds_double *Lgsy = L + mp.gsy, *Lgyy = L + mp.gyy;        // ... and the kept inner products [slot][slot]
+    const int c16 = lane & 15, q4 = lane >> 4;                // ... batch lane = (ring pair / age, quarter of the horizon)
+    lds_double2 *Los = (lds_double2 *)(L + mp.vec) + (t < COLS ? t : COLS - 1);      // parked pairs, one column per stage
     lds_double2 *Log = Los + COLS, *Lq = Los + 2 * COLS, *Lyp = Los + 3 * COLS;
     lds_double2 *Lgk = Los + 6 * COLS;                          // gradient at the current iterate (opts.ls_failure = 1 only)
     lds_double2 *LypE = (lds_double2 *)(L + mp.vec) + 3 * COLS + te;      // the same columns, by evaluation lane
     lds_double2 *Ly = (lds_double2 *)(L + mp.vec) + 4 * COLS + te;        // multipliers y (read by every evaluation)
     lds_double *Lvr = L + mp.vec + 2 * 5 * COLS + te;                     // reference speed of this stage
-    if (lane < m) { LS[lane * NS + N] = dbl2{0.0, 0.0}; LY[lane * NS + N] = dbl2{0.0, 0.0}; }
+    // an empty L-BFGS buffer is all zeros: the Gram form runs over all ten ages every time (gsy | gyy | S | Y are contiguous)
+#define NMPC_LB_ZERO()                                                                                  \
+    do {                                                                                                \
+        lds_double2 *z_ = (lds_double2 *)(L + mp.gsy);                                                  \
+        for (int i_ = lane; i_ < MAXMEM * MAXMEM + 2 * MAXMEM * NS; i_ += 64) z_[i_] = dbl2{0.0, 0.0};  \
+        if (lane < MAXMEM) Lrho[lane] = 0.0;                                                            \
+    } while (0)
     if (threadIdx.x < TEAM_CTL_INTS) ctl[threadIdx.x] = threadIdx.x == CTL_OWNERS ? a.team_owners : 0;
     __syncthreads();
     lds_double2 *Lreq = (lds_double2 *)(L + mp.req);      // this wave's request: u | r | d by stage
@@ -305,29 +376,32 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
         bool posted = false;                      // a request of the current iteration is open for the helpers
-#ifdef NMPC_PROFILE
-        { extern __shared__ long long nmpc_prof_lds[]; if (lane < 16) nmpc_prof_lds[4096 + lane] = 0; }
-        long long cyc_eval = 0, cyc_top = 0, cyc_post = 0, tk0 = 0, tk1 = 0;
-#define NMPC_TICK(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
-        NMPC_TICK(tk0);
+        // -DNMPC_PROF2 (scripts/sections.py): cycles of this instance by section of the loop -- 0 phase handlers in front of the batch, 1 the batch
+        // of inner products, 2 exit test / L-BFGS update, 3 the recurrences and the direction, 4 envelope, trial points, request, 5 the
+        // evaluation, 6 the consumption of the trials.  Every mark drains the LDS queue, so the sum is a little above the plain build's time.
+#ifdef NMPC_PROF2
+        long long pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf_last;
+#define NMPC_SEC_RAW(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define NMPC_SEC(acc) do { long long t_; NMPC_SEC_RAW(t_); acc += t_ - pf_last; pf_last = t_; } while (0)
+        NMPC_SEC_RAW(pf_last);
+#else
+#define NMPC_SEC(acc) do { } while (0)
 #endif
 
         for (;;) {
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
+            bool lb_batch = false;                     // this pass starts with the batch of inner products (f_back, f_begin)
             if (f_back) {
-                f_back = false;
                 if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }      // speculation discarded
                 lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
+                NMPC_LB_ZERO();
                 fbe_ok = false;
                 pk_Lc *= 2.0; gamma /= 2.0;
                 pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
-                { double gr_; pair_sum(fma(rv, rv, rw * rw), fma(gv, rv, gw * rw), lane, nr2, gr_); pk_gr = gr_; }
-                norm_r = sqrt(nr2);
-                lip_it++;
-                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+                lb_batch = true;
             }
             // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1) | (tau/4, ls_n+2)
             if (f_trials) {
@@ -363,11 +437,57 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 }
             }
             // ---------------------------------------------------------------- start of a PANOC step
+            if (f_begin) { rv = uv - hv; rw = uw - hw; lb_batch = true; }
+            NMPC_SEC(pf0);
+            // ---- the batch of inner products of this step (Gram-form L-BFGS, see the top of the file)
+            double gU = 0.0, gs1 = 0.0, gs2 = 0.0, gy1 = 0.0, gy2 = 0.0;
+            if (lb_batch) {
+                if (f_begin && iteration >= 1 && !lb_first) {
+                    const dbl2 os_ = *Los, og_ = *Log;
+                    gs1 = uv - os_.x; gs2 = uw - os_.y; gy1 = rv - og_.x; gy2 = rw - og_.y;
+                }
+                if (t < GRAM_NST && h == 0) {
+                    Lnv[t] = dbl2{gs1, gs2}; Lnv[GRAM_NST + t] = dbl2{gy1, gy2};
+                    Lnv[2 * GRAM_NST + t] = dbl2{rv, rw}; Lnv[3 * GRAM_NST + t] = dbl2{gv, gw};
+                }
+                // lane (c, q): X = (S_c, Y_c), Z = (y, r) for the ring pairs c < 10; (s, y) x (s, y) for c = 10; (r, g) x (r, r) for
+                // c = 11; (s, y) x (r, r) for c >= 12.  V1 = X1.Z1, V2 = X1.Z2, V3 = X2.Z1, V4 = X2.Z2 over the stages of quarter q.
+                const lds_double2 *X1 = (c16 < MAXMEM ? LS + c16 * NS : (c16 == 11 ? Lnv + 2 * GRAM_NST : Lnv)) + 5 * q4;
+                const lds_double2 *X2 = (c16 < MAXMEM ? LY + c16 * NS : (c16 == 11 ? Lnv + 3 * GRAM_NST : Lnv + GRAM_NST)) + 5 * q4;
+                const lds_double2 *Z1 = (c16 < MAXMEM ? Lnv + GRAM_NST : (c16 == 10 ? Lnv : Lnv + 2 * GRAM_NST)) + 5 * q4;
+                const lds_double2 *Z2 = (c16 < MAXMEM ? Lnv + 2 * GRAM_NST : (c16 == 10 ? Lnv + GRAM_NST : Lnv + 2 * GRAM_NST)) + 5 * q4;
+                double V1 = 0.0, V2 = 0.0, V3 = 0.0, V4 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    const dbl2 x1 = X1[e], x2 = X2[e], z1 = Z1[e], z2 = Z2[e];
+                    V1 = fma(x1.x, z1.x, V1); V1 = fma(x1.y, z1.y, V1);
+                    V2 = fma(x1.x, z2.x, V2); V2 = fma(x1.y, z2.y, V2);
+                    V3 = fma(x2.x, z1.x, V3); V3 = fma(x2.y, z1.y, V3);
+                    V4 = fma(x2.x, z2.x, V4); V4 = fma(x2.y, z2.y, V4);
+                }
+                // (q0 + q1) + (q2 + q3) of all four at once: row i of gU ends up with V(i + 1) summed over the quarters
+                swap_rows(V1, V2);
+                const double W12 = V1 + V2;
+                swap_rows(V3, V4);
+                double W34 = V3 + V4;
+                double W12b = W12;
+                swap_halves(W12b, W34);
+                gU = W12b + W34;
+                nr2 = lane_scalar(gU, 11);                       // <r, r>
+                pk_gr = lane_scalar(gU, 32 + 11);                // <g, r>
+                norm_r = sqrt(nr2);
+#ifdef NMPC_PROF2
+                { double keep = norm_r + gU; asm volatile("" : "+v"(keep)); }
+#endif
+            }
+            NMPC_SEC(pf1);
+            if (f_back) {
+                f_back = false;
+                lip_it++;
+                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+            }
             if (f_begin) {
                 f_begin = false;
-                rv = uv - hv; rw = uw - hw;
-                { double gr_; pair_sum(fma(rv, rv, rw * rw), fma(gv, rv, gw * rw), lane, nr2, gr_); pk_gr = gr_; }
-                norm_r = sqrt(nr2);
                 bool exit_now = false;
                 if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
                     if (a.op.akkt_gradient == 2) exit_now = true;
@@ -390,88 +510,68 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     lip_it = 0;
                     // ---- tentative L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
                     n_first = lb_first; n_head = lb_head; n_active = lb_active; n_H0 = pk_H0; n_take_old = false;
+                    bool took = false;                  // the pair of this step entered the buffer (as its newest: age 0)
                     if (lb_first) {
                         n_first = false; n_take_old = true;
                     } else {
-                        const dbl2 os_ = *Los, og_ = *Log;
-                        const double s1 = uv - os_.x, s2 = uw - os_.y, y1 = rv - og_.x, y2 = rw - og_.y;
-                        double ys, ss;
-                        pair_sum(fma(s1, y1, s2 * y2), fma(s1, s1, s2 * s2), lane, ys, ss);
+                        const double ss = lane_scalar(gU, 10), ys = lane_scalar(gU, 16 + 10);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
                         if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
                         if (__any(ok)) {
+                            took = true;
                             n_take_old = true;
-                            n_head = lb_head == 0 ? m - 1 : lb_head - 1;
-                            if (in && h == 0) { LS[n_head * NS + t] = dbl2{s1, s2}; LY[n_head * NS + t] = dbl2{y1, y2}; }
+                            // the ring always turns over its ten slots: the pair of age k sits in slot (head + k) mod 10
+                            n_head = lb_head == 0 ? MAXMEM - 1 : lb_head - 1;
+                            if (in && h == 0) { LS[n_head * NS + t] = dbl2{gs1, gs2}; LY[n_head * NS + t] = dbl2{gy1, gy2}; }
                             if (lane == 0) Lrho[n_head] = 1.0 / ys;
-                            n_H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
+                            const double yy = lane_scalar(gU, 48 + 10);
+                            n_H0 = ys / yy;
                             if (n_active < m) n_active++;
-                            NMPC_WAVE_SYNC();
+                            // kept inner products of the new pair (slot n_head) with the pairs that stay: column n_head of gsy
+                            // (<s_c, y>, row 0 of gU), row and column of gyy (<y_c, y>, row 2); the new pair is the newest, so its
+                            // own row of gsy is zero (gsy is strictly lower triangular by age), and so is the diagonal
+                            if (c16 < MAXMEM && q4 < 3) {
+                                const bool dg = c16 == n_head;
+                                lds_double *wa = q4 == 0 ? Lgsy + c16 * MAXMEM + n_head : (q4 == 1 ? Lgsy + n_head * MAXMEM + c16 : Lgyy + c16 * MAXMEM + n_head);
+                                const double wv = q4 == 1 ? 0.0 : (dg ? (q4 == 0 ? 0.0 : yy) : gU);
+                                *wa = wv;
+                                if (q4 == 2) Lgyy[n_head * MAXMEM + c16] = wv;
+                            }
+                            if (m < MAXMEM) {
+                                // a shorter memory (opts.lbfgs_memory < 10): the pair that has just reached age m leaves -- its slot goes back
+                                // to zeros, as every slot that holds no pair is
+                                const int ev = n_head + m >= MAXMEM ? n_head + m - MAXMEM : n_head + m;
+                                if (t <= GRAM_NST && h == 0) { LS[ev * NS + t] = dbl2{0.0, 0.0}; LY[ev * NS + t] = dbl2{0.0, 0.0}; }
+                                if (lane == 0) Lrho[ev] = 0.0;
+                                if (c16 < MAXMEM && q4 < 2) {
+                                    (q4 == 0 ? Lgsy : Lgyy)[c16 * MAXMEM + ev] = 0.0;
+                                    (q4 == 0 ? Lgsy : Lgyy)[ev * MAXMEM + c16] = 0.0;
+                                }
+                            }
                         }
                     }
-                    // ---- d = H r, two-loop recursion over the tentative buffer ----
+                    // ---- d = H r over the tentative buffer ----
                     dv = rv; dw = rw;
-                    if (n_active == MAXMEM && m == MAXMEM) {
-                        // full buffer (the steady state): branch-free, all pairs addressed statically from the head
-                        double alpha[MAXMEM];
-#pragma unroll
-                        for (int k = 0; k < MAXMEM; ++k) {
-                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
-                            const dbl2 s_ = LS[slot * NS + tt], y_ = LY[slot * NS + tt];
-                            const double al = Lrho[slot] * hdot<P>(s_.x, s_.y, dv, dw, lane);
-                            alpha[k] = al;
-                            dv = fma(-al, y_.x, dv); dw = fma(-al, y_.y, dw);
-                        }
+                    NMPC_SEC(pf2);
+                    if (n_active > 0) {
+                        // age k = lane & 15 of every row (lanes 10..15 idle along on slot 9; what they compute is never looked at)
+                        const int pk_ = c16 < MAXMEM ? (n_head + c16 >= MAXMEM ? n_head + c16 - MAXMEM : n_head + c16) : MAXMEM - 1;
+                        const int pkrow = pk_ * MAXMEM;
+                        double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
+                        if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }      // (the ring held the evicted pair)
+                        const double rho_k = Lrho[pk_];
+                        NMPC_GRAM_FWD(0); NMPC_GRAM_FWD(1); NMPC_GRAM_FWD(2); NMPC_GRAM_FWD(3); NMPC_GRAM_FWD(4);
+                        NMPC_GRAM_FWD(5); NMPC_GRAM_FWD(6); NMPC_GRAM_FWD(7); NMPC_GRAM_FWD(8); NMPC_GRAM_FWD(9);
+                        const double alv = rho_k * ga1;          // alpha_k in lane k: entry k of ga1 is final once step k has used it
+                        ga2 = n_H0 * ga2;
                         dv = n_H0 * dv; dw = n_H0 * dw;
-#pragma unroll
-                        for (int k = MAXMEM - 1; k >= 0; --k) {
-                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
-                            const dbl2 s_ = LS[slot * NS + tt], y_ = LY[slot * NS + tt];
-                            const double be = Lrho[slot] * hdot<P>(y_.x, y_.y, dv, dw, lane);
-                            const double ab = alpha[k] - be;
-                            dv = fma(ab, s_.x, dv); dw = fma(ab, s_.y, dw);
-                        }
-                    } else if (n_active > 0) {
-                        // pair k lives in ring slot (n_head + k) mod m; each trip fetches the NEXT pair from
-                        // LDS before it reduces the current one, so the LDS latency hides under the reduction
-                        double alpha[MAXMEM];
-                        int slot = n_head;
-                        dbl2 sc_ = LS[slot * NS + tt], yc_ = LY[slot * NS + tt];
-                        double rc_ = Lrho[slot];
-#pragma unroll
-                        for (int k = 0; k < MAXMEM; ++k) {
-                            alpha[k] = 0.0;
-                            if (k < n_active) {
-                                dbl2 sn_ = {0.0, 0.0}, yn_ = {0.0, 0.0};
-                                double rn_ = 0.0;
-                                if (k + 1 < n_active) {
-                                    slot = slot + 1 == m ? 0 : slot + 1;
-                                    sn_ = LS[slot * NS + tt]; yn_ = LY[slot * NS + tt]; rn_ = Lrho[slot];
-                                }
-                                const double al = rc_ * hdot<P>(sc_.x, sc_.y, dv, dw, lane);
-                                alpha[k] = al;
-                                dv = fma(-al, yc_.x, dv); dw = fma(-al, yc_.y, dw);
-                                if (k + 1 < n_active) { sc_ = sn_; yc_ = yn_; rc_ = rn_; }
-                            }
-                        }
-                        dv = n_H0 * dv; dw = n_H0 * dw;
-                        // (sc_, yc_, rc_) now hold the oldest pair, k = n_active - 1; walk back to the newest
-#pragma unroll
-                        for (int k = MAXMEM - 1; k >= 0; --k) {
-                            if (k < n_active) {
-                                dbl2 sn_ = {0.0, 0.0}, yn_ = {0.0, 0.0};
-                                double rn_ = 0.0;
-                                if (k > 0) {
-                                    slot = slot == 0 ? m - 1 : slot - 1;
-                                    sn_ = LS[slot * NS + tt]; yn_ = LY[slot * NS + tt]; rn_ = Lrho[slot];
-                                }
-                                const double be = rc_ * hdot<P>(yc_.x, yc_.y, dv, dw, lane);
-                                const double ab = alpha[k] - be;
-                                dv = fma(ab, sc_.x, dv); dw = fma(ab, sc_.y, dw);
-                                if (k > 0) { sc_ = sn_; yc_ = yn_; rc_ = rn_; }
-                            }
-                        }
+                        NMPC_GRAM_BWD(9); NMPC_GRAM_BWD(8); NMPC_GRAM_BWD(7); NMPC_GRAM_BWD(6); NMPC_GRAM_BWD(5);
+                        NMPC_GRAM_BWD(4); NMPC_GRAM_BWD(3); NMPC_GRAM_BWD(2); NMPC_GRAM_BWD(1); NMPC_GRAM_BWD(0);
                     }
+#ifdef NMPC_PROF2
+                    { double keep = dv + dw; asm volatile("" : "+v"(keep)); }
+#endif
+                    NMPC_SEC(pf3);
                     if (!fbe_ok) { fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
                     rhs_ls = fbe_u - pk_sigma * nr2;
                     tau = 1.0; ls_n = 0;
@@ -509,6 +609,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 f_start = false;
                 { const dbl2 y_ = *Ly; *Ly = dbl2{clampd(y_.x, -1e12, 1e12), clampd(y_.y, -1e12, 1e12)}; }      // y <- Pi_Y(y)
                 lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                NMPC_LB_ZERO();
                 // init evaluates u (points 0, 2) and u + h (point 1), h_i = max(1e-6 u_i, 1e-12)
                 const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
                 const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
@@ -532,9 +633,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 else if (lvl == 2u) __builtin_amdgcn_s_setprio(2);
                 else if (lvl >= 3u) __builtin_amdgcn_s_setprio(3);
             }
-#ifdef NMPC_PROFILE
-            NMPC_TICK(tk1); cyc_top += tk1 - tk0; tk0 = tk1;
-#endif
+            NMPC_SEC(pf4);
 #ifdef NMPC_MARKS
             asm volatile("; MARK 10");
 #endif
@@ -545,10 +644,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
             eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws);
-#ifdef NMPC_PROFILE
+#ifdef NMPC_PROF2
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
-            NMPC_TICK(tk1); cyc_eval += tk1 - tk0; tk0 = tk1;
 #endif
+            NMPC_SEC(pf5);
 #ifdef NMPC_MARKS
             asm volatile("; MARK 11");
 #endif
@@ -784,10 +883,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     }
                 }
             }
-#ifdef NMPC_PROFILE
+#ifdef NMPC_PROF2
             { double keep = uv + gv + hv + cost; asm volatile("" : "+v"(keep)); }
-            NMPC_TICK(tk1); cyc_post += tk1 - tk0; tk0 = tk1;
 #endif
+            NMPC_SEC(pf6);
         }
 
         // ------------------------------------------------------------------ parked: state out, into the pool
@@ -842,15 +941,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 s.cost = (double)__builtin_amdgcn_s_memrealtime();
                 s.delta_y_norm_over_c = Lpar[13]; s.penalty = Lpar[14];
             }
-#ifdef NMPC_PROFILE
-            {
-                extern __shared__ long long nmpc_prof_lds[];
-                const long long *e = nmpc_prof_lds + 4096;
-                s.last_problem_norm_fpr = (double)cyc_eval; s.delta_y_norm_over_c = (double)cyc_top; s.f2_norm = (double)cyc_post;
-                s.penalty = (double)e[0]; s.cost = (double)e[1]; s.solve_time_ms = (double)e[2];
-                s.num_cost_evals = (uint32_t)(e[3] / 100); s.num_grad_evals = (uint32_t)(e[4] / 100);
-                s.num_outer_iterations = (uint32_t)(e[5] / 100); s.num_inner_iterations = (uint32_t)(e[6] / 100);
-            }
+#ifdef NMPC_PROF2
+            s.last_problem_norm_fpr = (double)pf0; s.delta_y_norm_over_c = (double)pf1; s.f2_norm = (double)pf2;
+            s.penalty = (double)pf3; s.cost = (double)pf4; s.solve_time_ms = (double)pf5;
+            s.num_cost_evals = (uint32_t)(pf6 / 64);
 #endif
             a.st[inst] = s;
         }
@@ -941,6 +1035,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #undef pk_gr
 
 #undef NMPC_FETCH_GRAD
+#undef NMPC_LB_ZERO
+#undef NMPC_GRAM_FWD
+#undef NMPC_GRAM_BWD
 #undef NMPC_TAKE_TRIAL
 #undef NMPC_HALF_STEP
 #undef NMPC_FBE

@@ -22,7 +22,7 @@ class OrcOpts(C.Structure):
                 ("sufficient_decrease", C.c_double), ("lbfgs_memory", C.c_int32),
                 ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("max_total_inner", C.c_int32),
                 ("akkt_gradient", C.c_int32), ("ls_failure", C.c_int32), ("inner_status", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("lbfgs_form", C.c_int32)]
 
 
 class OrcStatus(C.Structure):

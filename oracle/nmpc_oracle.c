@@ -196,6 +196,20 @@ static double hdot(const hvec *a, const hvec *b, int P)
     return tree_sum_p(t, P);
 }
 
+/* The inner product of the Gram-form L-BFGS (N <= 20): the 20 (zero padded) stages in four quarters of five, each quarter one
+ * sequential fma chain over (v_t, w_t) from +0.0, the quarters combined as (q0 + q1) + (q2 + q3).  What a wavefront computes when
+ * lane (vector, quarter) runs its chain and the four wave rows are then added with two permlane swaps (nmpc_solve_hyb.h). */
+static double qdot(const hvec *a, const hvec *b)
+{
+    double q[4];
+    for (int i = 0; i < 4; ++i) {
+        double acc = 0.0;
+        for (int t = 5 * i; t < 5 * i + 5; ++t) { acc = fma(a->v[t], b->v[t], acc); acc = fma(a->w[t], b->w[t], acc); }
+        q[i] = acc;
+    }
+    return (q[0] + q[1]) + (q[2] + q[3]);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* per-instance data derived from p once per solve                                            */
 /* ------------------------------------------------------------------------------------------ */
@@ -238,7 +252,7 @@ void orc_default_opts(orc_opts *o)
     o->akkt_gradient = 1;
     o->ls_failure = 0;
     o->inner_status = 0;
-    o->reserved = 0;
+    o->lbfgs_form = 0;
 }
 
 static int check_problem(const orc_problem *pb)
@@ -524,12 +538,17 @@ int orc_eval(const orc_problem *pb, const double *p, const double *u, double c, 
 #define LBFGS_SY_EPSILON 1e-10
 #define LBFGS_CBFGS_EPSILON 1e-8     /* with cbfgs alpha = 1 */
 
+#define GRAM_M 10      /* pairs the Gram form carries (the hybrid kernel's ring): ages >= m, and inactive ages, are exactly zero */
+#define GRAM_NST 20    /* stages the quarter dot runs over (N <= 20, zero padded) */
 typedef struct {
     int m, active, first_old;
+    int gram;                      /* 1: the Gram form below (N <= 20: what nmpc_solve_hyb.h computes); 0: the two-loop recursion */
     hvec S[MAXMEM], Y[MAXMEM];     /* index 0 = newest */
     double rho[MAXMEM];
     double H0;
     hvec old_s, old_g;
+    /* Gram form, by age: SY[a][b] = <s_a, y_b> for a OLDER than b (a > b), zero otherwise; YY[a][b] = <y_a, y_b> */
+    double SY[GRAM_M][GRAM_M], YY[GRAM_M][GRAM_M];
 } lbfgs_t;
 
 typedef struct {
@@ -565,11 +584,19 @@ static void grad_and_half_step(const inst_t *I, panoc_t *c, const hvec *x)
 static void compute_fpr(const inst_t *I, panoc_t *c, const hvec *u)
 {
     for (int t = 0; t < I->P; ++t) { c->r.v[t] = u->v[t] - c->uh.v[t]; c->r.w[t] = u->w[t] - c->uh.w[t]; }
-    c->nr2 = hdot(&c->r, &c->r, I->P);
+    c->nr2 = c->lb.gram ? qdot(&c->r, &c->r) : hdot(&c->r, &c->r, I->P);
     c->norm_r = sqrt(c->nr2);
 }
 
-static void lbfgs_reset(lbfgs_t *lb) { lb->active = 0; lb->first_old = 1; }
+static void lbfgs_reset(lbfgs_t *lb)
+{
+    lb->active = 0; lb->first_old = 1;
+    if (lb->gram) {      /* the Gram form runs over all GRAM_M ages every time: what is not active is exactly zero */
+        memset(lb->S, 0, sizeof(hvec) * GRAM_M); memset(lb->Y, 0, sizeof(hvec) * GRAM_M);
+        memset(lb->rho, 0, sizeof(double) * GRAM_M);
+        memset(lb->SY, 0, sizeof(lb->SY)); memset(lb->YY, 0, sizeof(lb->YY));
+    }
+}
 
 /* lbfgs crate: update_hessian(g := gamma_fpr, s := u) with sy-epsilon and C-BFGS safeguards */
 static void lbfgs_update(const inst_t *I, lbfgs_t *lb, const hvec *r, const hvec *u, double norm_r)
@@ -581,7 +608,7 @@ static void lbfgs_update(const inst_t *I, lbfgs_t *lb, const hvec *r, const hvec
         s.v[t] = u->v[t] - lb->old_s.v[t]; s.w[t] = u->w[t] - lb->old_s.w[t];
         y.v[t] = r->v[t] - lb->old_g.v[t]; y.w[t] = r->w[t] - lb->old_g.w[t];
     }
-    const double ys = hdot(&s, &y, P), ss = hdot(&s, &s, P);
+    const double ys = lb->gram ? qdot(&s, &y) : hdot(&s, &y, P), ss = lb->gram ? qdot(&s, &s) : hdot(&s, &s, P);
     if (ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON) return;
     if (!(ys / ss > LBFGS_CBFGS_EPSILON * norm_r)) return;
     lb->old_s = *u;
@@ -590,8 +617,50 @@ static void lbfgs_update(const inst_t *I, lbfgs_t *lb, const hvec *r, const hvec
     lb->S[0] = s;
     lb->Y[0] = y;
     lb->rho[0] = 1.0 / ys;
+    if (lb->gram) {
+        /* every pair ages by one; the new pair's column of SY and row / column of YY are measured against the pairs that stay.
+         * (Each entry is a function of two stored vectors only, so keeping it equals recomputing it.) */
+        for (int a = lb->m - 1; a > 0; --a)
+            for (int b = lb->m - 1; b > 0; --b) { lb->SY[a][b] = lb->SY[a - 1][b - 1]; lb->YY[a][b] = lb->YY[a - 1][b - 1]; }
+        for (int a = 1; a < lb->m; ++a) {
+            lb->SY[a][0] = qdot(&lb->S[a], &y);
+            lb->SY[0][a] = 0.0;
+            lb->YY[a][0] = lb->YY[0][a] = qdot(&lb->Y[a], &y);
+        }
+        lb->SY[0][0] = 0.0;
+        lb->YY[0][0] = qdot(&y, &y);
+        lb->H0 = ys / lb->YY[0][0];
+    } else
     lb->H0 = ys / hdot(&y, &y, P);
     if (lb->active < lb->m) lb->active++;
+}
+
+/* d := H d in the Gram form (N <= 20; nmpc_solve_hyb.h): the coefficients of the two-loop recursion,
+ *   alpha_j = rho_j <s_j, q_j>,  beta_j = rho_j <y_j, z_j>,
+ * come out of two recurrences over the inner products <s_k, r>, <y_k, r>, SY, YY instead of twenty dependent reductions over the
+ * horizon; the vector updates are those of the two-loop recursion, in its order.  All GRAM_M ages take part every time (what is
+ * not active is zero).  SY is strictly lower triangular by age, so entry k of a1 is final once step k has used it, and entry k
+ * of a2 once step k of the second recurrence has. */
+static void lbfgs_apply_gram(const inst_t *I, const lbfgs_t *lb, hvec *d)
+{
+    const int P = I->P;
+    double a1[GRAM_M], a2[GRAM_M], alv[GRAM_M];
+    if (lb->active == 0) return;
+    const hvec r = *d;
+    for (int k = 0; k < GRAM_M; ++k) { a1[k] = qdot(&lb->S[k], &r); a2[k] = qdot(&lb->Y[k], &r); }
+    for (int j = 0; j < GRAM_M; ++j) {
+        const double al = lb->rho[j] * a1[j];
+        for (int k = 0; k < GRAM_M; ++k) { a1[k] = fma(-al, lb->SY[k][j], a1[k]); a2[k] = fma(-al, lb->YY[k][j], a2[k]); }
+        for (int t = 0; t < P; ++t) { d->v[t] = fma(-al, lb->Y[j].v[t], d->v[t]); d->w[t] = fma(-al, lb->Y[j].w[t], d->w[t]); }
+    }
+    for (int k = 0; k < GRAM_M; ++k) { alv[k] = lb->rho[k] * a1[k]; a2[k] = lb->H0 * a2[k]; }
+    for (int t = 0; t < P; ++t) { d->v[t] = lb->H0 * d->v[t]; d->w[t] = lb->H0 * d->w[t]; }
+    for (int j = GRAM_M - 1; j >= 0; --j) {
+        const double be = lb->rho[j] * a2[j];
+        const double ab = alv[j] - be;
+        for (int k = 0; k < GRAM_M; ++k) a2[k] = fma(ab, lb->SY[j][k], a2[k]);
+        for (int t = 0; t < P; ++t) { d->v[t] = fma(ab, lb->S[j].v[t], d->v[t]); d->w[t] = fma(ab, lb->S[j].w[t], d->w[t]); }
+    }
 }
 
 /* two-loop recursion, q := H q */
@@ -698,7 +767,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         double cost_uh = o->psi;
         int n_back = 0, n_trials = 0;
         for (int it = 0; it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && c->L < MAX_LIPSCHITZ_CONSTANT; ++it) {
-            const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - hdot(&c->g, &c->r, P)
+            const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - (c->lb.gram ? qdot(&c->g, &c->r) : hdot(&c->g, &c->r, P))
                              + (GAMMA_L_COEFF / (2.0 * c->gamma)) * c->nr2;
             if (!(cost_uh > rhs)) break;
             lbfgs_reset(&c->lb);
@@ -713,7 +782,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         c->sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * c->gamma);
         /* L-BFGS buffer update and direction */
         lbfgs_update(I, &c->lb, &c->r, u, c->norm_r);
-        if (c->iteration > 0) { c->d = c->r; lbfgs_apply(I, &c->lb, &c->d); }
+        if (c->iteration > 0) { c->d = c->r; if (c->lb.gram) lbfgs_apply_gram(I, &c->lb, &c->d); else lbfgs_apply(I, &c->lb, &c->d); }
         if (c->iteration == 0) {
             /* first iteration: plain forward-backward step */
             *u = c->uh;
@@ -799,6 +868,9 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
     prepare(pb, p, I);
     const int P = I->P, n2 = pb->nobs + pb->ndyn;
     pc->lb.m = opts->lbfgs_memory;
+    /* the L-BFGS arithmetic follows the kernel that solves this horizon: Gram form for N <= 20 (nmpc_solve_hyb.h), the two-loop
+     * recursion otherwise; opts->lbfgs_form = 1 forces the two-loop recursion (tests compare the two) */
+    pc->lb.gram = N <= GRAM_NST && opts->lbfgs_memory <= GRAM_M && opts->lbfgs_form != 1;
     hvec u, y, yplus;
     load_hvec(&u, u_io, N, 1);
     load_hvec(&y, y0, N, 0);

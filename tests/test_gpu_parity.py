@@ -137,7 +137,6 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
 
 
 @pytest.mark.parametrize("name,env,kernel", [("cfg1", {}, "nmpc_solve_hyb_kernel<ShapeDefault>"),
-                                             ("cfg1", {"NMPC_LAYOUT": "dual"}, "nmpc_solve_dual_kernel"),
                                              ("cfg1", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
                                              ("cfg3", {}, "nmpc_solve_hyb_kernel<ShapeNobs50>"),
                                              ("cfg3", {"NMPC_SHAPE": "any"}, "nmpc_solve_hyb_kernel<ShapeAny>"),
@@ -146,8 +145,10 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
                                              ("cfg2", {"NMPC_TEAM_HELP": "0"}, "nmpc_solve_hyb2_kernel<ShapeN40>"),
                                              ("cfg2", {"NMPC_TEAM_OWNERS": "4"}, "nmpc_solve_hyb2_kernel<ShapeN40>")])
 def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
-    """Shapes with a specialised kernel: the run-time-shape kernel and the two-point kernel (used for
-    20 < N_hor <= 32) must give the same bits on them; the handle reports which kernel runs."""
+    """Shapes with a specialised kernel: the run-time-shape kernel must give the same bits on them; the handle reports which
+    kernel runs.  (The two-point kernel is no alternative for N_hor <= 20 any more: the hybrid kernel's L-BFGS is in the Gram
+    form, the oracle follows the kernel that serves the horizon, and the two-point kernel is checked on its own horizons,
+    20 < N_hor <= 32, in the shape sweep.)"""
     from mpc_trajectory_generator_amd.solver import BatchSolver
     cfg = named_config(name)
     P = synthetic_batch(cfg, 11, 40, 4242, synthetic_circles=(name == "cfg3"))
@@ -435,15 +436,13 @@ def test_nonfinite_cost_with_finite_controls_matches_the_oracle(solvers):
         assert not np.all(np.isfinite(gpu[2]["cost"][bad]) & np.isfinite(gpu[2]["last_problem_norm_fpr"][bad]))
 
 
-@pytest.mark.parametrize("name,B", [("cfg1", 4096), ("cfg1", 1), ("cfg2", 512), ("cfg1-dual", 512)])
+@pytest.mark.parametrize("name,B", [("cfg1", 4096), ("cfg1", 1), ("cfg2", 512), ("n27-dual", 512)])
 def test_per_instance_solve_time(solvers, name, B, monkeypatch):
     """status.solve_time_ms is THIS instance's first-start -> finish time on the device clock (the reference reads
     it per solve, src/mpc/mpc_generator.py:214, and derives its loop overhead from it, src/path_generator.py:387,402-403):
     positive, never above the kernel time of the batch, and growing with the work the instance needed."""
     from mpc_trajectory_generator_amd.solver import BatchSolver
-    if name.endswith("-dual"):
-        monkeypatch.setenv("NMPC_LAYOUT", "dual")
-    cfg = named_config(name.split("-")[0])
+    cfg = load_config(N_hor=27) if name == "n27-dual" else named_config(name)      # (20 < N_hor <= 32: the two-point kernel)
     P = synthetic_batch(cfg, 11, B, 31337)
     s = BatchSolver(cfg, max_batch=B)
     try:
