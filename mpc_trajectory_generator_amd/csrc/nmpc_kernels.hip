@@ -298,6 +298,8 @@ __device__ __forceinline__ unsigned long long circle_near_mask(const double *p, 
 #ifdef NMPC_PROFILE
 #define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_evt[i] += t_ - nmpc_evl; nmpc_evl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 __device__ long long nmpc_dummy_;
+#elif defined(NMPC_PROF2) && NMPC_PROF2 == 2      // scripts/sections.py: cycles of the evaluation by section, accumulated in registers of the caller
+#define NMPC_EVTICK(i) do { if (nmpc_pe) { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_pe[i] += t_ - nmpc_pe[7]; nmpc_pe[7] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #elif defined(NMPC_MARKS)       // scripts/isa_stats.py: section markers in the ISA dump
 #define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -310,11 +312,13 @@ template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, 
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
-                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, WinState *ws = nullptr)
+                                         double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, WinState *ws = nullptr,
+                                         long long *nmpc_pe = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
+    (void)nmpc_pe;
     // every stage lane of the tri layout is inside a 20-stage horizon; lanes 60..63 then hold
     // don't-care values that no cross-lane operation lets into the other lanes (nmpc_device.h)
     constexpr bool FULL = P == 20 && SH::N == 20;

@@ -381,6 +381,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         // evaluation, 6 the consumption of the trials.  Every mark drains the LDS queue, so the sum is a little above the plain build's time.
 #ifdef NMPC_PROF2
         long long pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf_last;
+        long long pe[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // NMPC_PROF2 == 2: the evaluation's own sections (eval_psi's NMPC_EVTICK marks), pe[7] = last mark
 #define NMPC_SEC_RAW(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define NMPC_SEC(acc) do { long long t_; NMPC_SEC_RAW(t_); acc += t_ - pf_last; pf_last = t_; } while (0)
         NMPC_SEC_RAW(pf_last);
@@ -643,7 +644,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zXv = lane_get(xv, zsrcX), zXw = lane_get(xw, zsrcX);
             const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
+#if defined(NMPC_PROF2) && NMPC_PROF2 == 2
+            NMPC_SEC_RAW(pe[7]);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, pe);
+#else
             eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws);
+#endif
 #ifdef NMPC_PROF2
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
 #endif
@@ -945,6 +951,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             s.last_problem_norm_fpr = (double)pf0; s.delta_y_norm_over_c = (double)pf1; s.f2_norm = (double)pf2;
             s.penalty = (double)pf3; s.cost = (double)pf4; s.solve_time_ms = (double)pf5;
             s.num_cost_evals = (uint32_t)(pf6 / 64);
+#if NMPC_PROF2 == 2
+            // rollout | stage cost + cross-track | accelerations, ALM term, cost sum | touched obstacles + adjoint head | adjoint sweep | circle scan | ellipse scan
+            s.last_problem_norm_fpr = (double)pe[0]; s.delta_y_norm_over_c = (double)pe[1]; s.f2_norm = (double)pe[2];
+            s.penalty = (double)pe[3]; s.cost = (double)pe[4]; s.solve_time_ms = (double)pe[5];
+            s.num_cost_evals = (uint32_t)(pe[6] / 64);
+#endif
 #endif
             a.st[inst] = s;
         }

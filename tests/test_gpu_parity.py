@@ -442,6 +442,7 @@ def test_per_instance_solve_time(solvers, name, B, monkeypatch):
     it per solve, src/mpc/mpc_generator.py:214, and derives its loop overhead from it, src/path_generator.py:387,402-403):
     positive, never above the kernel time of the batch, and growing with the work the instance needed."""
     from mpc_trajectory_generator_amd.solver import BatchSolver
+    from mpc_trajectory_generator_amd.config import load_config
     cfg = load_config(N_hor=27) if name == "n27-dual" else named_config(name)      # (20 < N_hor <= 32: the two-point kernel)
     P = synthetic_batch(cfg, 11, B, 31337)
     s = BatchSolver(cfg, max_batch=B)
