@@ -27,6 +27,7 @@ constexpr int NZ = 20;         // reference configs/default.yaml:35
 constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
 constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
 constexpr int GRAM_NST = 20;   // stages the Gram-form L-BFGS of the hybrid kernel runs over (N_hor <= 20, zero padded)
+constexpr int OBS_STRIDE = 4;  // doubles per static circle in LDS: xs ys r^2 r
 constexpr int SEG_STRIDE = 5;  // doubles per reference segment in LDS (odd: the per-lane window gathers of eval_psi spread over all banks)
 // team mode of the hybrid kernel (nmpc_solve_hyb.h): four waves per workgroup; a wave without work of its own evaluates
 // line-search trials for its siblings.  Request = u, r, d by stage (3 x 24 pairs); one result area = three trials'
@@ -57,7 +58,7 @@ struct LdsMap {
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
     int par;     // up to 20 parked solver scalars (hybrid kernel)
     int seg;     // SEG_STRIDE = 5 per reference segment (40 B): s1x s1y dx dy 1/(|d|^2 + 1e-16)
-    int obs;     // 3 per static circle: xs ys r^2
+    int obs;     // OBS_STRIDE per static circle: xs ys r^2 r
     int f2;      // n2 penalty values
     int dyn;     // NDYN_MAX x 6 x dyn_stride per-stage ellipse data
     int dyn_stride;  // columns per (ellipse, field): 24 / 32 for the three- / two-point layouts, N rounded up to even for one point
@@ -157,7 +158,7 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     mp.cw = o;  o += CW_NCOEF;
     mp.par = o; o += 20;
     mp.seg = o; o += SEG_STRIDE * (N + 5);
-    mp.obs = o; o += 3 * (nobs + 4);
+    mp.obs = o; o += OBS_STRIDE * (nobs + 4);
     const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
     // (three-point layout: only the cost-layer kernel writes F2, and it has no parked vectors -- the array shares their place)
     mp.f2 = o;  o += P == 20 ? 0 : points * (nobs + ndyn + 1);
@@ -211,9 +212,10 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     for (int k = t; k < ((nobs + 4) & ~3); k += P) {       // padded to a multiple of 4 with inert zero circles (slot `nobs` always is one)
         const bool real = k < nobs;
         const double r = real ? ps[3 * k + 2] : 0.0;
-        L[mp.obs + 3 * k] = real ? ps[3 * k] : 0.0;
-        L[mp.obs + 3 * k + 1] = real ? ps[3 * k + 1] : 0.0;
-        L[mp.obs + 3 * k + 2] = r * r;
+        L[mp.obs + OBS_STRIDE * k] = real ? ps[3 * k] : 0.0;
+        L[mp.obs + OBS_STRIDE * k + 1] = real ? ps[3 * k + 1] : 0.0;
+        L[mp.obs + OBS_STRIDE * k + 2] = r * r;
+        L[mp.obs + OBS_STRIDE * k + 3] = r > 0.0 ? r : -1e30;      // (obstacle certificate: an empty slot is infinitely far away)
     }
     const double *pd = ps + 3 * nobs;
     {
@@ -268,8 +270,21 @@ struct WinState {
     double xr, yr, mo2;
 };
 #ifdef NMPC_WIN_STATS
-__device__ unsigned long long nmpc_win_stats[2];       // evaluations that tried the window | of which fell back to the full scan
+__device__ unsigned long long nmpc_win_stats[4];       // evaluations that tried the window | of which fell back to the full scan | that tried the obstacle certificate | of which scanned
 #endif
+// Obstacle certificate (eval_psi, oc != nullptr).  The activity scan of an evaluation only decides WHICH circles / ellipses have a stage of
+// the wave inside them (the touched ones are then summed exactly); from one evaluation to the next that set rarely changes.  So a lane
+// remembers where its stage was at the wave's last scan and how far that was -- at least -- from every obstacle the scan found
+// untouched (distance to the circle's edge; for an ellipse to the disc of its larger half axis around its centre; for the culled scan
+// also to the culling radius), and the wave remembers the scan's verdict.  While every stage has moved by less than its clearance no
+// untouched obstacle can have been entered: the old verdict is a superset of the true one, and a superfluous member contributes exactly
+// zero (its sum is +0.0, no lane is inside it) -- the scan is skipped and the result is bit for bit the scanning evaluation's.  The
+// clearances come from v_sqrt_f64 / v_rsq_f64 (approximate) with 1 % + 1e-6 taken off: they only decide whether the scan runs.
+struct ObsCert {
+    double xo, yo, m2;             // this lane: the stage's position at the last scan, squared clearance there (0: scan next time)
+    unsigned long long act;        // the wave: circles ...
+    unsigned act_dyn;              // ... and ellipses the last scan found touched
+};
 // Is the windowed minimum `best` (squared) the global one?  With a2 = |p - p_ref|^2 and mo2 = the squared clearance of the window at
 // p_ref, every segment outside the window is at least sqrt(mo2) - |p - p_ref| away from p (distances are 1-Lipschitz), so it is if
 // sqrt(best) + |p - p_ref| < sqrt(mo2)  <=>  t = mo2 - a2 - best > 0 and t^2 > 4 a2 best.  The margins (1e-5 relative on squared
@@ -313,7 +328,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
                                          double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, WinState *ws = nullptr,
-                                         long long *nmpc_pe = nullptr)
+                                         ObsCert *oc = nullptr, long long *nmpc_pe = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
@@ -488,8 +503,17 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     double pen = 0.0;
     unsigned long long act = 0ull;      // wave-uniform: circles some stage is inside of
     unsigned act_dyn = 0u;              // wave-uniform: ellipses some stage is inside of
-    double dyh[NDYN_MAX];
-    {
+    bool scan = true;
+    if (oc) {
+        const double ox = xn - oc->xo, oy = yn - oc->yo;
+        const bool sure = fma(ox, ox, oy * oy) < oc->m2;
+        if (!__any(in_r & !sure)) { act = oc->act; act_dyn = oc->act_dyn; scan = false; }
+#ifdef NMPC_WIN_STATS
+        if (lane == 0) { atomicAdd(&nmpc_win_stats[2], 1ull); if (scan) atomicAdd(&nmpc_win_stats[3], 1ull); }
+#endif
+    }
+    if (scan) {
+        double mg = __builtin_inf();        // (oc) this lane's clearance from the obstacles the scan finds untouched
         const lds_double *ob = L + mp.obs;
         const int nobs4 = (nobs + 3) & ~3;
         if constexpr (CULL) {
@@ -499,7 +523,9 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             if (todo != all) {
                 const double rx = xn - x0, ry = yn - y0;
                 const double rg = 0.999 * a.cull_radius;
-                if (__any(in_r & !(fma(rx, rx, ry * ry) <= rg * rg))) todo = all;
+                const double ro2 = fma(rx, rx, ry * ry);
+                if (__any(in_r & !(ro2 <= rg * rg))) todo = all;
+                else if (oc) mg = rg - __builtin_amdgcn_sqrt(ro2);      // the set holds while the stage stays inside the radius
             }
             while (todo) {                                  // four circles per trip; slot `nobs` holds an inert zero circle
                 int kk[4];
@@ -508,32 +534,37 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
                     kk[j] = todo ? __builtin_ctzll(todo) : nobs;
                     todo &= todo - (todo ? 1ull : 0ull);
                 }
-                double od[12];
+                double od[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const lds_double *oj = ob + 3 * kk[j];
-                    od[3 * j] = oj[0]; od[3 * j + 1] = oj[1]; od[3 * j + 2] = oj[2];
+                    const lds_double *oj = ob + OBS_STRIDE * kk[j];
+                    od[4 * j] = oj[0]; od[4 * j + 1] = oj[1]; od[4 * j + 2] = oj[2]; od[4 * j + 3] = oc ? oj[3] : 0.0;
                 }
                 NMPC_SCHED_BARRIER();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
-                    const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
+                    const double dx = xn - od[4 * j], dy = yn - od[4 * j + 1];
+                    const double h = fma(-dy, dy, fma(-dx, dx, od[4 * j + 2]));       // (:112)
                     if (__any(in_r & (h > 0.0))) act |= 1ull << (kk[j] & 63);          // (the inert circle never is)
+                    else if (oc) mg = fmin(mg, __builtin_amdgcn_sqrt(od[4 * j + 2] - h) - od[4 * j + 3]);
                 }
             }
         } else {
 #pragma unroll SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1
-        for (int k = 0; k < nobs4; k += 4, ob += 12) {      // activity scan: four circles per trip, one ballot each
-            double od[12];
+        for (int k = 0; k < nobs4; k += 4, ob += 4 * OBS_STRIDE) {      // activity scan: four circles per trip, one ballot each
+            double od[16];
 #pragma unroll
-            for (int f = 0; f < 12; ++f) od[f] = ob[f];
+            for (int j = 0; j < 4; ++j) {
+                od[4 * j] = ob[OBS_STRIDE * j]; od[4 * j + 1] = ob[OBS_STRIDE * j + 1]; od[4 * j + 2] = ob[OBS_STRIDE * j + 2];
+                od[4 * j + 3] = oc ? ob[OBS_STRIDE * j + 3] : 0.0;
+            }
             NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const double dx = xn - od[3 * j], dy = yn - od[3 * j + 1];
-                const double h = fma(-dy, dy, fma(-dx, dx, od[3 * j + 2]));       // (:112)
+                const double dx = xn - od[4 * j], dy = yn - od[4 * j + 1];
+                const double h = fma(-dy, dy, fma(-dx, dx, od[4 * j + 2]));       // (:112)
                 if (__any(in_r & (h > 0.0))) act |= 1ull << (k + j);
+                else if (oc) mg = fmin(mg, __builtin_amdgcn_sqrt(od[4 * j + 2] - h) - od[4 * j + 3]);
             }
         }
         }
@@ -547,17 +578,23 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int k = 0; k < NDYN_MAX; ++k) {
-                dyh[k] = 0.0;
                 if (k < ndyn) {
                     const double ca = dv_[k][DY_CA], sa = dv_[k][DY_SA];
                     const double dx = xn - dv_[k][DY_EX], dy = yn - dv_[k][DY_EY];
                     const double ea = fma(dx, ca, dy * sa);
                     const double eb = fma(dx, sa, -(dy * ca));
                     const double h = fma(-(eb * eb), dv_[k][DY_IRY2], fma(-(ea * ea), dv_[k][DY_IRX2], 1.0));   // (:118)
-                    dyh[k] = in ? fmax(h, 0.0) : 0.0;
-                    if (__any(in_r & (dyh[k] > 0.0))) act_dyn |= 1u << k;
+                    if (__any(in_r & (h > 0.0))) act_dyn |= 1u << k;
+                    else if (oc)      // the ellipse lies inside the disc of its larger half axis
+                        mg = fmin(mg, __builtin_amdgcn_sqrt(fma(dx, dx, dy * dy)) - __builtin_amdgcn_rsq(fmin(dv_[k][DY_IRX2], dv_[k][DY_IRY2])));
                 }
             }
+        }
+        if (oc) {
+            const double m = fma(0.99, mg, -1e-6);
+            oc->xo = xn; oc->yo = yn;
+            oc->m2 = m > 0.0 ? (m < 1e100 ? m * m : 1e200) : 0.0;
+            oc->act = act; oc->act_dyn = act_dyn;
         }
         NMPC_EVTICK(6);     // ellipse scan
     }
@@ -584,7 +621,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             const bool two = rem != 0ull;
             const int k1 = two ? __builtin_ctzll(rem) : k0;
             rem &= rem - (two ? 1ull : 0ull);
-            const lds_double *o0 = L + mp.obs + 3 * k0, *o1 = L + mp.obs + 3 * k1;
+            const lds_double *o0 = L + mp.obs + OBS_STRIDE * k0, *o1 = L + mp.obs + OBS_STRIDE * k1;
             const double ax = o0[0], ay = o0[1], ar = o0[2], bx = o1[0], by = o1[1], br = o1[2];
             const double dx0 = xn - ax, dy0 = yn - ay, dx1 = xn - bx, dy1 = yn - by;
             const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar)), h1 = fma(-dy1, dy1, fma(-dx1, dx1, br));
@@ -602,17 +639,17 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
             if (act_dyn & (1u << k)) {
-                const double f2 = group_sum<P>(dyh[k], lane);
+                const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
+                const double irx2 = dyn.get(k, DY_IRX2), iry2 = dyn.get(k, DY_IRY2);
+                const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
+                const double ea = fma(dx, ca, dy * sa);
+                const double eb = fma(dx, sa, -(dy * ca));
+                const double h = fma(-(eb * eb), iry2, fma(-(ea * ea), irx2, 1.0));      // (:118)
+                const double f2 = group_sum<P>(in ? fmax(h, 0.0) : 0.0, lane);
                 if (WRITE_F2 && t == 0) L[f2off + nobs + k] = f2;
                 pen = fma(f2, f2, pen);
                 if (want_grad) {
                     const double wk = -2.0 * (c * f2);
-                    const double ca = dyn.get(k, DY_CA), sa = dyn.get(k, DY_SA);
-                    const double irx2 = dyn.get(k, DY_IRX2), iry2 = dyn.get(k, DY_IRY2);
-                    const double dx = xn - dyn.get(k, DY_EX), dy = yn - dyn.get(k, DY_EY);
-                    const double ea = fma(dx, ca, dy * sa);
-                    const double eb = fma(dx, sa, -(dy * ca));
-                    const double h = fma(-(eb * eb), iry2, fma(-(ea * ea), irx2, 1.0));
                     if (h > 0.0) {
                         const double A = ea * irx2, Bq = eb * iry2;
                         const double hx = fma(A, ca, Bq * sa);
@@ -1828,8 +1865,8 @@ int nmpc_test_divsqrt_host(nmpc_handle *h, int n, const double *a, const double 
 // experiments only (scripts/win_stats.py): windowed cross-track searches and how many of them fell back to the full scan
 int nmpc_debug_win_stats(unsigned long long *out, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nmpc::nmpc_win_stats), 2 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) { const unsigned long long z[2] = {0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(nmpc::nmpc_win_stats), z, sizeof z); }
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nmpc::nmpc_win_stats), 4 * sizeof(unsigned long long));      // windows: tried | fell back; obstacle certificates: tried | scanned
+    if (e == hipSuccess && reset) { const unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(nmpc::nmpc_win_stats), z, sizeof z); }
     return e == hipSuccess ? NMPC_OK : NMPC_ERR_HIP;
 }
 #endif

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
         WinState ws = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
+        ObsCert oc = {0.0, 0.0, 0.0, 0ull, 0u};                      // ... and its obstacle certificate
         if (lane == 0) Lpar[19] = (double)inst;                      // (helpers tell by it whether their own windows are still this instance's)
         unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
         if constexpr (CULL) {
@@ -646,9 +647,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
 #if defined(NMPC_PROF2) && NMPC_PROF2 == 2
             NMPC_SEC_RAW(pe[7]);
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, pe);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, &oc, pe);
 #else
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, &oc);
 #endif
 #ifdef NMPC_PROF2
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     WinState ws_h = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this helper lane's cross-track window, valid for the instance `ws_inst`
+    ObsCert oc_h = {0.0, 0.0, 0.0, 0ull, 0u};                      // ... and its obstacle certificate, likewise
     double ws_inst = -1.0;
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
@@ -1010,11 +1012,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         if constexpr (CULL) { const double nb_ = Lw[mp.par + 18]; near_w = ((unsigned long long)(unsigned)__double2hiint(nb_) << 32) | (unsigned)__double2loint(nb_); }
         if constexpr (WIN > 0) {            // another instance's reference: what this lane knew about its window is void
             const double inst_w = Lw[mp.par + 19];
-            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; }
+            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
-        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h);
+        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, &oc_h);
         if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
-            if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; }
+            if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute

@@ -15,7 +15,7 @@ if sys.argv[1] == "child":
     out = {}
     P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=1000), synthetic_circles=name == "cfg3", random_dyn=name == "cfg4")
     sol.solve(P)
-    buf = (ctypes.c_ulonglong * 2)()
+    buf = (ctypes.c_ulonglong * 4)()
     if hasattr(lib, "nmpc_debug_win_stats"):
         lib.nmpc_debug_win_stats(buf, 1)
     ms = []
@@ -26,6 +26,8 @@ if sys.argv[1] == "child":
         lib.nmpc_debug_win_stats(buf, 0)
         out["searches"], out["fallbacks"] = int(buf[0]), int(buf[1])
         out["fallback_share"] = round(buf[1] / max(buf[0], 1), 4)
+        out["obstacle_certificates"], out["obstacle_scans"] = int(buf[2]), int(buf[3])
+        out["obstacle_scan_share"] = round(buf[3] / max(buf[2], 1), 4)
     out["ms"] = round(min(ms), 2)
     out["checksum"] = float(st["num_inner_iterations"].astype(np.float64).sum() + st["cost"].sum())
     print(json.dumps(out))
