@@ -273,6 +273,36 @@ __device__ __forceinline__ double from_next<20>(double v, int lane)
     return (lane >= 48 && (lane & 3) == 3) ? 0.0 : o;
 }
 
+// inclusive prefix sum AND the inclusive sum of the stage before (`excl`; 0.0 at stage 0): what from_prev(group_prefix(v)) would
+// deliver, without a second exchange -- in the tri layout the value a tail quad's first stage needs from its row (the inclusive sum
+// of stage 15) is the very carry the prefix sum has just fetched.
+template <int P>
+__device__ __forceinline__ double group_prefix_ex(double v, int lane, double &excl)
+{
+    const double incl = group_prefix<P>(v, lane);
+    excl = from_prev<P>(incl, lane, 0.0);
+    return incl;
+}
+template <>
+__device__ __forceinline__ double group_prefix_ex<20>(double v, int lane, double &excl)
+{
+    const bool tail = lane >= 48;
+    double o = dpp_mov<0x111>(v);
+    v = v + ((tail && (lane & 3) < 1) ? 0.0 : o);
+    o = dpp_mov<0x112>(v);
+    v = v + ((tail && (lane & 3) < 2) ? 0.0 : o);
+    o = dpp_mov_old<0x114, 0x7>(zero_pair(), v);
+    v = v + o;
+    o = dpp_mov_old<0x118, 0x7>(o, v);
+    v = v + o;
+    const int q = (lane - 48) >> 2;
+    const double carry = lane_get(v, (tail && lane < 60) ? 16 * q + 15 : lane);     // last entry of block 0
+    const double incl = v + (tail ? carry : 0.0);
+    const double sh = dpp_mov<0x111>(incl);                                          // row_shr:1, zero fill at the start of a row
+    excl = (tail && (lane & 3) == 0) ? carry : sh;
+    return incl;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sin and cos: Cody-Waite reduction by pi/2 in three fma steps + fdlibm minimax kernels (Horner, fma)
 // ---------------------------------------------------------------------------------------------

@@ -56,7 +56,7 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 struct LdsMap {
     int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
-    int par;     // up to 20 parked solver scalars (hybrid kernel)
+    int par;     // up to 24 parked solver scalars (hybrid kernel)
     int seg;     // SEG_STRIDE = 5 per reference segment (40 B): s1x s1y dx dy 1/(|d|^2 + 1e-16)
     int obs;     // OBS_STRIDE per static circle: xs ys r^2 r
     int f2;      // n2 penalty values
@@ -156,7 +156,7 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     int o = 0;
     mp.sc = o;  o += 20;
     mp.cw = o;  o += CW_NCOEF;
-    mp.par = o; o += 20;
+    mp.par = o; o += 24;
     mp.seg = o; o += SEG_STRIDE * (N + 5);
     mp.obs = o; o += OBS_STRIDE * (nobs + 4);
     const int points = P == 64 ? 1 : 3;               // F2 arrays: one per query point of a pass (eval kernel: per group slice)
@@ -281,10 +281,15 @@ __device__ unsigned long long nmpc_win_stats[4];       // evaluations that tried
 // zero (its sum is +0.0, no lane is inside it) -- the scan is skipped and the result is bit for bit the scanning evaluation's.  The
 // clearances come from v_sqrt_f64 / v_rsq_f64 (approximate) with 1 % + 1e-6 taken off: they only decide whether the scan runs.
 struct ObsCert {
-    double xo, yo, m2;             // this lane: the stage's position at the last scan, squared clearance there (0: scan next time)
-    unsigned long long act;        // the wave: circles ...
-    unsigned act_dyn;              // ... and ellipses the last scan found touched
+    double xo, yo, m2;             // this lane: the stage's position at the wave's last scan, squared clearance there (0: scan next time).  (A reference
+                                   // point shared with the cross-track window was measured: four registers less, but either certificate's failure then
+                                   // runs both scans -- 10 % of the evaluations instead of 1 %, headline + 6 %.)
+    // the wave: circles and ellipses the last scan found touched.  Kept in VECTOR registers (every lane the same value; read back with
+    // v_readfirstlane): as scalar-register values in the select chains of the caller they crash ROCm 7.2's greedy register allocator
+    // (VirtRegAuxInfo::isRematerializable, iterative-ilp, the Nobs = 50 instantiation)
+    int act_lo, act_hi, act_dyn;
 };
+__device__ __forceinline__ int opaque_i(int x) { asm("" : "+v"(x)); return x; }
 // Is the windowed minimum `best` (squared) the global one?  With a2 = |p - p_ref|^2 and mo2 = the squared clearance of the window at
 // p_ref, every segment outside the window is at least sqrt(mo2) - |p - p_ref| away from p (distances are 1-Lipschitz), so it is if
 // sqrt(best) + |p - p_ref| < sqrt(mo2)  <=>  t = mo2 - a2 - best > 0 and t^2 > 4 a2 best.  The margins (1e-5 relative on squared
@@ -349,14 +354,17 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const double xf = sc[SC_XF], yf = sc[SC_YF], thf = sc[SC_THF];
 
     // rollout (:88-90) as three prefix sums
-    const double thn = fma(ts, group_prefix<P>(zw, lane), th0);
-    const double th = from_prev<P>(thn, lane, th0);
+    // (the pre-update state of a stage is the post-update state of the stage before: the same fma on the prefix sum of the stage before,
+    // which the scan hands over with its own carry exchange -- group_prefix_ex)
+    double ew_, ex_, ey_;
+    const double thn = fma(ts, group_prefix_ex<P>(zw, lane, ew_), th0);
+    const double th = t == 0 ? th0 : fma(ts, ew_, th0);
     double sn, cs;
     sincos_cw_t(th, (const lds_double *)(L + mp.cw), sn, cs);
-    const double xn = fma(ts, group_prefix<P>(zv * cs, lane), x0);
-    const double yn = fma(ts, group_prefix<P>(zv * sn, lane), y0);
-    const double xp = from_prev<P>(xn, lane, x0);
-    const double yp = from_prev<P>(yn, lane, y0);
+    const double xn = fma(ts, group_prefix_ex<P>(zv * cs, lane, ex_), x0);
+    const double yn = fma(ts, group_prefix_ex<P>(zv * sn, lane, ey_), y0);
+    const double xp = t == 0 ? x0 : fma(ts, ex_, x0);
+    const double yp = t == 0 ? y0 : fma(ts, ey_, y0);
 
     const double half_c = 0.5 * c;
     NMPC_EVTICK(0);     // rollout
@@ -507,7 +515,11 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     if (oc) {
         const double ox = xn - oc->xo, oy = yn - oc->yo;
         const bool sure = fma(ox, ox, oy * oy) < oc->m2;
-        if (!__any(in_r & !sure)) { act = oc->act; act_dyn = oc->act_dyn; scan = false; }
+        if (!__any(in_r & !sure)) {
+            act = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(oc->act_hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(oc->act_lo);
+            act_dyn = (unsigned)__builtin_amdgcn_readfirstlane(oc->act_dyn);
+            scan = false;
+        }
 #ifdef NMPC_WIN_STATS
         if (lane == 0) { atomicAdd(&nmpc_win_stats[2], 1ull); if (scan) atomicAdd(&nmpc_win_stats[3], 1ull); }
 #endif
@@ -594,7 +606,7 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
             const double m = fma(0.99, mg, -1e-6);
             oc->xo = xn; oc->yo = yn;
             oc->m2 = m > 0.0 ? (m < 1e100 ? m * m : 1e200) : 0.0;
-            oc->act = act; oc->act_dyn = act_dyn;
+            oc->act_lo = opaque_i((int)(unsigned)act); oc->act_hi = opaque_i((int)(unsigned)(act >> 32)); oc->act_dyn = opaque_i((int)act_dyn);
         }
         NMPC_EVTICK(6);     // ellipse scan
     }

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     constexpr bool FULL = SH::N == PE;
     constexpr bool CULL = SH::NOBS > NMPC_CULL_MIN || SH::NOBS < 0;      // many circle slots: scan only those the robot can reach (eval_psi)
     constexpr int WIN = NMPC_WIN;                             // windowed cross-track search: half width in segments (eval_psi)
+    constexpr bool OBSC = SH::N > 0;                          // obstacle certificate (eval_psi): the shape-specialised kernels only -- the run-time-shape kernel has no registers left for it
     const bool inea = FULL ? true : ine;
     const LdsMap mp = the_map<SH, PE>(a);
     const int n2 = shape_nobs<SH>(a) + shape_ndyn<SH>(a);
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #define pk_H0 Lpar[9]
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
+#define pk_fbe_u Lpar[20]       /* FBE at the current iterate */
 #define pk_gr Lpar[12]          /* <grad psi, r> of the current iterate: summed together with ||r||^2, used by the Lipschitz test */
     /* Lpar[13], Lpar[14]: first start (100 MHz clock) and migration count; Lpar[15..17]: c, 1 / max(c, 1) and gamma of the request */
 
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
         WinState ws = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
-        ObsCert oc = {0.0, 0.0, 0.0, 0ull, 0u};                      // ... and its obstacle certificate
+        ObsCert oc = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate
         if (lane == 0) Lpar[19] = (double)inst;                      // (helpers tell by it whether their own windows are still this instance's)
         unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
         if constexpr (CULL) {
@@ -333,14 +335,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         // gradient_u_previous (AKKT residual): zero at the start of a solve, carried across its inner solves
         *Lq = (resumed && in) ? dbl2{pk[4 * N + 2 * t], pk[4 * N + 2 * t + 1]} : dbl2{0.0, 0.0};
         double gv = 0, gw = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
-        double pv = 0, pw = 0;                    // line-search trial point being consumed
-        double xv = 0, xw = 0;                    // query point X of THIS half (-> evaluation points 0 and 1)
-        double yqv = 0, yqw = 0;                  // query point Y (-> evaluation point 2)
+        // (the query points of a pass -- X of this half -> evaluation points 0 and 1, Y -> point 2 -- and the trial point being consumed live
+        // inside one pass: they are declared in the loop body, so that they do not occupy registers from one pass to the next)
         bool need_grad = true;
-        double cost = 0, gamma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0;
+        double cost = 0, gamma = 0, tau = 1, rhs_ls = 0;
+        pk_fbe_u = 0.0;
         pk_Lc = 0.0; pk_sigma = 0.0; pk_H0 = 1.0;
-        double fbe_u = 0;                         // FBE at the current iterate, valid while fbe_ok (an accepted
-        bool fbe_ok = false;                      // trial's FBE is the next iteration's: same operands, same bits)
+        bool fbe_ok = false;                      // pk_fbe_u holds the FBE at the current iterate (an accepted trial's FBE is the next iteration's: same operands, same bits)
         int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
         bool lb_first = true;
         // tentative L-BFGS update of the current iteration (committed when the Lipschitz test passes)
@@ -391,6 +392,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #endif
 
         for (;;) {
+            double xv = 0, xw = 0, yqv = 0, yqw = 0;       // query points of this pass: a phase handler below sets them
+            double nr2 = 0, norm_r = 0;                    // ||r||^2, ||r|| of the step this pass starts (the batch below); the last ||r|| stays in pk_last_fpr
+            double pv = 0, pw = 0;                         // line-search trial point being consumed (after the evaluation)
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
             bool lb_batch = false;                     // this pass starts with the batch of inner products (f_back, f_begin)
             if (f_back) {
@@ -478,6 +482,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 nr2 = lane_scalar(gU, 11);                       // <r, r>
                 pk_gr = lane_scalar(gU, 32 + 11);                // <g, r>
                 norm_r = sqrt(nr2);
+                pk_last_fpr = norm_r;
 #ifdef NMPC_PROF2
                 { double keep = norm_r + gU; asm volatile("" : "+v"(keep)); }
 #endif
@@ -574,8 +579,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     { double keep = dv + dw; asm volatile("" : "+v"(keep)); }
 #endif
                     NMPC_SEC(pf3);
-                    if (!fbe_ok) { fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
-                    rhs_ls = fbe_u - pk_sigma * nr2;
+                    if (!fbe_ok) { pk_fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
+                    rhs_ls = pk_fbe_u - pk_sigma * nr2;
                     tau = 1.0; ls_n = 0;
                     xv = h ? fma(-1.0, dv, fma(-0.0, rv, uv)) : hv;      // X: u_bar | u+(tau = 1) = u - 0 r - d
                     xw = h ? fma(-1.0, dw, fma(-0.0, rw, uw)) : hw;
@@ -600,9 +605,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
                                          : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
                 inner_total += num_iter;
-                pk_last_fpr = norm_r; pk_last_cost = cost;
+                pk_last_cost = cost;                                     // (pk_last_fpr: the norm of the last step started)
                 uv = hv; uw = hw;                                        // PANOC returns the feasible half step
-                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
+                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(pk_last_fpr);
                 if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
                 else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
             }
@@ -647,9 +652,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
 #if defined(NMPC_PROF2) && NMPC_PROF2 == 2
             NMPC_SEC_RAW(pe[7]);
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, &oc, pe);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, pe);
 #else
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, &oc);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr);
 #endif
 #ifdef NMPC_PROF2
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
@@ -660,6 +665,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #endif
             const double psiA = point_scalar(psi, 0), psiB = point_scalar(psi, 1), psiC = point_scalar(psi, 2);
             // one trial of the current direction: psi, grad psi were evaluated by query point K at step tau
+            // (Measured and not taken: the envelopes of all three points formed in the evaluation layout right after the evaluation -- as the
+            // helpers form theirs -- so that the search is three comparisons and one gradient fetch.  It saves 64 vector instructions per
+            // trial after the first but costs 70 on EVERY pass; the bulk of a batch accepts its first trial: headline 40.2 -> 43 ms.)
 #define NMPC_TAKE_TRIAL(PSI, SRC) NMPC_TAKE_TRIAL_(PSI, NMPC_FETCH_GRAD((SRC), gv, gw))
 #define NMPC_TAKE_TRIAL_(PSI, FETCH)                                                   \
             do {                                                                       \
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                         }
                         if (rejected) f_trials = true;
                         else if (exhausted) f_fb = true;
-                        else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+                        else { uv = pv; uw = pw; pk_fbe_u = lhs; fbe_ok = true; f_end = true; }
                     }
                 }
             } else if (state == D_LS) {
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 if (rejected) NMPC_TAKE_TRIAL(psiC, src2);
                 if (rejected) f_trials = true;
                 else if (exhausted) f_fb = true;
-                else { uv = pv; uw = pw; fbe_u = lhs; fbe_ok = true; f_end = true; }
+                else { uv = pv; uw = pw; pk_fbe_u = lhs; fbe_ok = true; f_end = true; }
             } else if (state == D_FB) {
                 // psi, grad psi at u_bar: the plain forward-backward step (as in iteration 0)
                 n_grad++;
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     WinState ws_h = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this helper lane's cross-track window, valid for the instance `ws_inst`
-    ObsCert oc_h = {0.0, 0.0, 0.0, 0ull, 0u};                      // ... and its obstacle certificate, likewise
+    ObsCert oc_h = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate, likewise
     double ws_inst = -1.0;
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
@@ -1014,7 +1022,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double inst_w = Lw[mp.par + 19];
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
-        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, &oc_h);
+        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, OBSC ? &oc_h : nullptr);
         if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
             if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
@@ -1047,6 +1055,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #undef pk_sigma
 #undef pk_c_lip
 #undef pk_gr
+#undef pk_fbe_u
 
 #undef NMPC_FETCH_GRAD
 #undef NMPC_LB_ZERO
