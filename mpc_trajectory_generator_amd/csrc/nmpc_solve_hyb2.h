@@ -40,8 +40,8 @@ __device__ __forceinline__ D2 clamp2(D2 x, double lo, double hi) { return D2{cla
 __device__ __forceinline__ double gsum2(D2 v, int lane) { return group_sum<20>(v.a + v.b, lane); }
 __device__ __forceinline__ D2 gprefix2(D2 v, int lane)
 {
-    const double W = group_prefix<20>(v.a + v.b, lane);
-    const double E = from_prev<20>(W, lane, 0.0);
+    double E;
+    const double W = group_prefix_ex<20>(v.a + v.b, lane, E);      // (the exclusive sum comes with the scan's own carry exchange)
     return D2{E + v.a, W};
 }
 __device__ __forceinline__ D2 gsuffix2(D2 v, int lane)
@@ -101,7 +101,7 @@ __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
     mp.cw = o;  o += CW_NCOEF;
     mp.par = o; o += 20;
     mp.seg = o; o += SEG_STRIDE * (N + 5);
-    mp.obs = o; o += 3 * (nobs + 4);
+    mp.obs = o; o += OBS_STRIDE * (nobs + 4);
     mp.f2 = o;  o += 3 * (nobs + ndyn + 1);
     mp.rho = o; o += MAXMEM;
     o = (o + 1) & ~1;
@@ -138,9 +138,10 @@ __device__ __forceinline__ void prepare_instance2(const KArgs &a, lds_double *L,
     for (int k = lane; k < ((nobs + 3) & ~3); k += 64) {               // padded to a multiple of 4 with inert zero circles
         const bool real = k < nobs;
         const double r = real ? ps[3 * k + 2] : 0.0;
-        L[mp.obs + 3 * k] = real ? ps[3 * k] : 0.0;
-        L[mp.obs + 3 * k + 1] = real ? ps[3 * k + 1] : 0.0;
-        L[mp.obs + 3 * k + 2] = r * r;
+        L[mp.obs + OBS_STRIDE * k] = real ? ps[3 * k] : 0.0;
+        L[mp.obs + OBS_STRIDE * k + 1] = real ? ps[3 * k + 1] : 0.0;
+        L[mp.obs + OBS_STRIDE * k + 2] = r * r;
+        L[mp.obs + OBS_STRIDE * k + 3] = r > 0.0 ? r : -1e30;      // (obstacle certificate: an empty slot is infinitely far away)
     }
     const double *pd = ps + 3 * nobs;
     if (lane < 48) {                                                   // stage `lane`: one column of the ellipse tables
@@ -192,10 +193,15 @@ __device__ __forceinline__ D2 dyn2(const lds_double *L, const LdsMap2 &mp, int t
 // psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen) for the query point whose stages 2 te, 2 te + 1 this lane holds.
 // The arithmetic per stage is that of eval_psi (nmpc_kernels.hip); what differs is which lane holds which stage.
 // ---------------------------------------------------------------------------------------------
+// the obstacle certificate of eval_psi (nmpc_kernels.hip: ObsCert), one per stage of the lane
+struct ObsCert2 {
+    D2 xo, yo, m2;
+    int act_lo, act_hi, act_dyn;
+};
 template <class SH, bool WRITE_F2 = false, int WIN = 0>
 __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const LdsMap2 &mp, int f2off, int lane, int te, D2 zv, D2 zw,
                                           double c, double cbar_inv, D2 yv, D2 yw, bool want_grad, double &psi, double &pen_out,
-                                          D2 &gv, D2 &gw, D2 &av_out, D2 &aw_out, WinState *ws = nullptr)
+                                          D2 &gv, D2 &gw, D2 &av_out, D2 &aw_out, WinState *ws = nullptr, ObsCert2 *oc = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const double ts = a.pb.ts, inv_ts = a.inv_ts;
@@ -365,36 +371,65 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
     double pen = 0.0;
     unsigned long long act = 0ull;
     unsigned act_dyn = 0u;
-    D2 dyh[NDYN_MAX];
-    {
+    bool scan = true;
+    if (oc) {       // the activity scan is skipped while no stage has moved as far as its clearance from the untouched obstacles (eval_psi)
+        const D2 ox = xn - oc->xo, oy = yn - oc->yo;
+        const D2 o2 = fma2(ox, ox, oy * oy);
+        if (!__any((ra & !(o2.a < oc->m2.a)) | (rb & !(o2.b < oc->m2.b)))) {
+            act = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(oc->act_hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(oc->act_lo);
+            act_dyn = (unsigned)__builtin_amdgcn_readfirstlane(oc->act_dyn);
+            scan = false;
+        }
+#ifdef NMPC_WIN_STATS
+        if (lane == 0) { atomicAdd(&nmpc_win_stats[2], 1ull); if (scan) atomicAdd(&nmpc_win_stats[3], 1ull); }
+#endif
+    }
+    if (scan) {
+        D2 mg = d2s(__builtin_inf());
         const lds_double *ob = L + mp.obs;
         const int nobs4 = (nobs + 3) & ~3;
 #pragma unroll SH::NOBS >= 0 && SH::NOBS <= 16 ? 16 : 1
-        for (int k = 0; k < nobs4; k += 4, ob += 12) {
-            double od[12];
+        for (int k = 0; k < nobs4; k += 4, ob += 4 * OBS_STRIDE) {
+            double od[16];
 #pragma unroll
-            for (int f = 0; f < 12; ++f) od[f] = ob[f];
+            for (int j = 0; j < 4; ++j) {
+                od[4 * j] = ob[OBS_STRIDE * j]; od[4 * j + 1] = ob[OBS_STRIDE * j + 1]; od[4 * j + 2] = ob[OBS_STRIDE * j + 2];
+                od[4 * j + 3] = oc ? ob[OBS_STRIDE * j + 3] : 0.0;
+            }
             NMPC_SCHED_BARRIER();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (SH::NOBS >= 0 && SH::NOBS <= 16 && k + j >= SH::NOBS) continue;      // (unrolled: the padding slots of a fixed shape cost nothing)
-                const D2 dx = xn - d2s(od[3 * j]), dy = yn - d2s(od[3 * j + 1]);
-                const D2 h = fma2(-dy, dy, fma2(-dx, dx, d2s(od[3 * j + 2])));    // (:112)
+                const D2 dx = xn - d2s(od[4 * j]), dy = yn - d2s(od[4 * j + 1]);
+                const D2 h = fma2(-dy, dy, fma2(-dx, dx, d2s(od[4 * j + 2])));    // (:112)
                 if (__any((ra & (h.a > 0.0)) | (rb & (h.b > 0.0)))) act |= 1ull << (k + j);
+                else if (oc) {
+                    mg.a = fmin(mg.a, __builtin_amdgcn_sqrt(od[4 * j + 2] - h.a) - od[4 * j + 3]);
+                    mg.b = fmin(mg.b, __builtin_amdgcn_sqrt(od[4 * j + 2] - h.b) - od[4 * j + 3]);
+                }
             }
         }
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
-            dyh[k] = d2s(0.0);
             if (k < ndyn) {
                 const D2 ca = dyn2(L, mp, te, k, DY_CA), sa = dyn2(L, mp, te, k, DY_SA);
                 const D2 dx = xn - dyn2(L, mp, te, k, DY_EX), dy = yn - dyn2(L, mp, te, k, DY_EY);
                 const D2 ea = fma2(dx, ca, dy * sa);
                 const D2 eb = fma2(dx, sa, -(dy * ca));
-                const D2 h = fma2(-(eb * eb), dyn2(L, mp, te, k, DY_IRY2), fma2(-(ea * ea), dyn2(L, mp, te, k, DY_IRX2), d2s(1.0)));   // (:118)
-                dyh[k] = D2{ina ? fmax(h.a, 0.0) : 0.0, inb ? fmax(h.b, 0.0) : 0.0};
-                if (__any((ra & (dyh[k].a > 0.0)) | (rb & (dyh[k].b > 0.0)))) act_dyn |= 1u << k;
+                const D2 irx2 = dyn2(L, mp, te, k, DY_IRX2), iry2 = dyn2(L, mp, te, k, DY_IRY2);
+                const D2 h = fma2(-(eb * eb), iry2, fma2(-(ea * ea), irx2, d2s(1.0)));   // (:118)
+                if (__any((ra & (h.a > 0.0)) | (rb & (h.b > 0.0)))) act_dyn |= 1u << k;
+                else if (oc) {      // the ellipse lies inside the disc of its larger half axis
+                    mg.a = fmin(mg.a, __builtin_amdgcn_sqrt(fma(dx.a, dx.a, dy.a * dy.a)) - __builtin_amdgcn_rsq(fmin(irx2.a, iry2.a)));
+                    mg.b = fmin(mg.b, __builtin_amdgcn_sqrt(fma(dx.b, dx.b, dy.b * dy.b)) - __builtin_amdgcn_rsq(fmin(irx2.b, iry2.b)));
+                }
             }
+        }
+        if (oc) {
+            const D2 m = fma2(0.99, mg, -1e-6);
+            oc->xo = xn; oc->yo = yn;
+            oc->m2 = D2{m.a > 0.0 ? (m.a < 1e100 ? m.a * m.a : 1e200) : 0.0, m.b > 0.0 ? (m.b < 1e100 ? m.b * m.b : 1e200) : 0.0};
+            oc->act_lo = opaque_i((int)(unsigned)act); oc->act_hi = opaque_i((int)(unsigned)(act >> 32)); oc->act_dyn = opaque_i((int)act_dyn);
         }
     }
     // ---- adjoint, first term: the cross-track error through the arg-min segment of each stage ----
@@ -423,7 +458,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
         for (unsigned long long rem = act; rem;) {
             const int k0 = __builtin_ctzll(rem);
             rem &= rem - 1;
-            const lds_double *o0 = L + mp.obs + 3 * k0;
+            const lds_double *o0 = L + mp.obs + OBS_STRIDE * k0;
             const double ax = o0[0], ay = o0[1], ar = o0[2];
             const D2 dx0 = xn - d2s(ax), dy0 = yn - d2s(ay);
             const D2 h0 = fma2(-dy0, dy0, fma2(-dx0, dx0, d2s(ar)));
@@ -439,17 +474,17 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
 #pragma unroll
         for (int k = 0; k < NDYN_MAX; ++k) {
             if (act_dyn & (1u << k)) {
-                const double f2 = gsum2(dyh[k], lane);
+                const D2 ca = dyn2(L, mp, te, k, DY_CA), sa = dyn2(L, mp, te, k, DY_SA);
+                const D2 irx2 = dyn2(L, mp, te, k, DY_IRX2), iry2 = dyn2(L, mp, te, k, DY_IRY2);
+                const D2 dx = xn - dyn2(L, mp, te, k, DY_EX), dy = yn - dyn2(L, mp, te, k, DY_EY);
+                const D2 ea = fma2(dx, ca, dy * sa);
+                const D2 eb = fma2(dx, sa, -(dy * ca));
+                const D2 h = fma2(-(eb * eb), iry2, fma2(-(ea * ea), irx2, d2s(1.0)));      // (:118)
+                const double f2 = gsum2(D2{ina ? fmax(h.a, 0.0) : 0.0, inb ? fmax(h.b, 0.0) : 0.0}, lane);
                 if (WRITE_F2 && te == 0) L[f2off + nobs + k] = f2;
                 pen = fma(f2, f2, pen);
                 if (want_grad) {
                     const double wk = -2.0 * (c * f2);
-                    const D2 ca = dyn2(L, mp, te, k, DY_CA), sa = dyn2(L, mp, te, k, DY_SA);
-                    const D2 irx2 = dyn2(L, mp, te, k, DY_IRX2), iry2 = dyn2(L, mp, te, k, DY_IRY2);
-                    const D2 dx = xn - dyn2(L, mp, te, k, DY_EX), dy = yn - dyn2(L, mp, te, k, DY_EY);
-                    const D2 ea = fma2(dx, ca, dy * sa);
-                    const D2 eb = fma2(dx, sa, -(dy * ca));
-                    const D2 h = fma2(-(eb * eb), iry2, fma2(-(ea * ea), irx2, d2s(1.0)));
                     const D2 A = ea * irx2, Bq = eb * iry2;
                     const D2 hx = fma2(A, ca, Bq * sa);
                     const D2 hy = fma2(A, sa, -(Bq * ca));
@@ -628,6 +663,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         if (lane == 0) Lpar[19] = -1.0;                      // (nmpc_solve_hyb.h: the id is away while the tables change)
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
         WinState ws[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // this lane's cross-track windows
+        ObsCert2 oc = {d2s(0.0), d2s(0.0), d2s(0.0), 0, 0, 0};      // ... and its obstacle certificate
         if (lane == 0) Lpar[19] = (double)inst;              // (helpers tell by it whether their windows are still this instance's)
 
         // a fresh instance starts from the caller's u0 / y0, a resumed one from its parked state (acquired by pool_pop): u | y | previous gradient
@@ -943,7 +979,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             ld4<H2_ENT>(Pts + 2 * H2_ENT * (q), te, zv, zw);
             ld4<H2_COLS>(Cy, te, yv, yw);
             NMPC2_TK(1);
-            eval_psi2<SH, false, NMPC_WIN2>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ws);
+            eval_psi2<SH, false, NMPC_WIN2>(a, L, mp, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, need_grad, psi, pen, egv, egw, eav, eaw, ws, &oc);
             NMPC2_TK(2);
             if (need_grad) st4<H2_ENT>(Grd + 2 * H2_ENT * (q), te, egv, egw);
             NMPC_WAVE_SYNC();
@@ -1220,6 +1256,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     WinState ws_h[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // valid for instance `ws_inst`
+    ObsCert2 oc_h = {d2s(0.0), d2s(0.0), d2s(0.0), 0, 0, 0};
     double ws_inst = -1.0;
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
@@ -1253,10 +1290,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         D2 egv = d2s(0.0), egw = d2s(0.0), eav, eaw;
         {                                   // another instance's reference: what this lane knew about its windows is void
             const double inst_w = Lw[mp.par + 19];
-            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; }
+            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }
         }
-        eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ws_h);
-        if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; }      // (the owner moved on meanwhile)
+        eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ws_h, &oc_h);
+        if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }      // (the owner moved on meanwhile)
         // the trial's forward-backward envelope, in the evaluation layout (the same canonical sums as the state layout's)
         const D2 s1_ = fma2(-gam_w, egv, zv), s2_ = fma2(-gam_w, egw, zw);
         const D2 x1_ = D2{s1_.a - (inea ? clampd(s1_.a, vmin, vmax) : s1_.a), s1_.b - (ineb ? clampd(s1_.b, vmin, vmax) : s1_.b)};
