@@ -81,8 +81,10 @@ struct LdsMap2 {
     int pts;      // query points of a pass: X of half 0 | X of half 1 | Y, 24 entries of 4 doubles each
     int grd;      // gradients of the pass's three points, the same shape
     int req;      // team request: u | r | d, the same shape
-    int vec;      // 7 parked state-layout vectors: 32 entries of 4 doubles each
+    int vec;      // 7 parked state-layout vectors: 24 entries of 4 doubles each (state lanes 24..31 share entry 23: zeros)
+    int gsy, gyy; // Gram-form L-BFGS (nmpc_solve_hyb.h): the kept inner products [slot][slot]
     int S, Y;     // L-BFGS ring: MAXMEM slots x 21 entries (20 lane pairs + a zero column) of 4 doubles
+    int nv;       // ... the four vectors of an iteration -- s | y | r | g -- in the ring's shape
     int total;
 };
 #ifndef NMPC_WIN2
@@ -91,7 +93,7 @@ struct LdsMap2 {
 // in front of an EXEC restore, codegen_check.py; W = 2 is exact and repeatable under all four scheduler strategies, only not faster.)
 #define NMPC_WIN2 1
 #endif
-constexpr int H2_COLS = 32, H2_NS = 21, H2_ENT = 24;
+constexpr int H2_COLS = 24, H2_NS = 21, H2_ENT = 24;
 constexpr int TEAM2_AREA_DOUBLES = 3 * H2_ENT * 4 + 8;
 __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
 {
@@ -102,7 +104,7 @@ __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
     mp.par = o; o += 20;
     mp.seg = o; o += SEG_STRIDE * (N + 5);
     mp.obs = o; o += OBS_STRIDE * (nobs + 4);
-    mp.f2 = o;  o += 3 * (nobs + ndyn + 1);
+    mp.f2 = o;  o += 0;                 // (only the cost-layer kernel writes F2, and it has no parked vectors: the array shares their place)
     mp.rho = o; o += MAXMEM;
     o = (o + 1) & ~1;
     mp.dyn = o; o += NDYN_MAX * 6 * 48;
@@ -111,8 +113,14 @@ __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
     mp.grd = o; o += 3 * H2_ENT * 4;
     mp.req = o; o += 3 * H2_ENT * 4;
     mp.vec = o; o += 7 * H2_COLS * 4;
+    mp.f2 = mp.vec;
+    if (7 * H2_COLS * 4 < 3 * (nobs + ndyn + 1)) o = mp.vec + 3 * (nobs + ndyn + 1);
+    o = (o + 1) & ~1;
+    mp.gsy = o; o += MAXMEM * MAXMEM;   // gsy | gyy | S | Y are contiguous (zeroed together when the buffer is reset)
+    mp.gyy = o; o += MAXMEM * MAXMEM;
     mp.S = o;   o += MAXMEM * H2_NS * 4;
     mp.Y = o;   o += MAXMEM * H2_NS * 4;
+    mp.nv = o;  o += 4 * H2_NS * 4;
     mp.total = (o + 1) & ~1;
     return mp;
 }
@@ -627,7 +635,17 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
     const bool inea = FULL ? true : rea, ineb = FULL ? true : reb;
     const int n2 = shape_nobs<SH>(a) + shape_ndyn<SH>(a);
     const int f2off = mp.f2 + q * (n2 + 1);
-    const int tz = in ? t : 0, tt = in ? t : H2_NS - 1;             // LDS entry of this state lane (ring: the zero column beyond the horizon)
+    const int tz = in ? t : 0, tt = t < H2_NS - 1 ? t : H2_NS - 1;  // LDS entry of this state lane (ring: the zero column beyond its 20 entries; entries beyond the horizon are zeros)
+    const int tc = t < H2_COLS ? t : H2_COLS - 1;                   // ... in the parked columns (lanes 24..31 share the last one: zeros)
+    lds_double2 *Lnv = (lds_double2 *)(L + mp.nv);                  // Gram-form L-BFGS (nmpc_solve_hyb.h): s | y | r | g of the iteration ...
+    lds_double *Lgsy = L + mp.gsy, *Lgyy = L + mp.gyy;              // ... the kept inner products
+    const int c16 = lane & 15, q4 = lane >> 4;                      // ... batch lane = (ring pair / age, quarter of the horizon)
+#define NMPC2_LB_ZERO()                                                                                    \
+    do {                                                                                                   \
+        lds_double2 *z_ = (lds_double2 *)(L + mp.gsy);                                                     \
+        for (int i_ = lane; i_ < MAXMEM * MAXMEM + 4 * MAXMEM * H2_NS; i_ += 64) z_[i_] = dbl2{0.0, 0.0};  \
+        if (lane < MAXMEM) Lrho[lane] = 0.0;                                                               \
+    } while (0)
     lds_double2 *LS = (lds_double2 *)(L + mp.S);
     lds_double2 *LY = (lds_double2 *)(L + mp.Y);
     lds_double *Lrho = L + mp.rho;
@@ -636,7 +654,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
     lds_double2 *Cos = V + 2 * H2_COLS * 0, *Cog = V + 2 * H2_COLS * 1, *Cq = V + 2 * H2_COLS * 2, *Cyp = V + 2 * H2_COLS * 3, *Cy = V + 2 * H2_COLS * 4,
                 *Cgk = V + 2 * H2_COLS * 6;
     lds_double2 *Pts = (lds_double2 *)(L + mp.pts), *Grd = (lds_double2 *)(L + mp.grd), *Lreq = (lds_double2 *)(L + mp.req);
-    if (lane < m) { st4<H2_NS>(LS + 2 * H2_NS * (lane), H2_NS - 1, d2s(0.0), d2s(0.0)); st4<H2_NS>(LY + 2 * H2_NS * (lane), H2_NS - 1, d2s(0.0), d2s(0.0)); }
     if (threadIdx.x < TEAM_CTL_INTS) ctl[threadIdx.x] = threadIdx.x == CTL_OWNERS ? a.team_owners : 0;
     __syncthreads();
     unsigned team_seq = 0;
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         {   // gradient_u_previous (AKKT residual): zero at the start of a solve, carried across its inner solves
             const double *qb = pk + 4 * N;
             const bool ld = resumed && ina;
-            st4<H2_COLS>(Cq, t, D2{ld ? qb[4 * t] : 0.0, (ld && inb) ? qb[4 * t + 2] : 0.0}, D2{ld ? qb[4 * t + 1] : 0.0, (ld && inb) ? qb[4 * t + 3] : 0.0});
+            st4<H2_COLS>(Cq, tc, D2{ld ? qb[4 * t] : 0.0, (ld && inb) ? qb[4 * t + 2] : 0.0}, D2{ld ? qb[4 * t + 1] : 0.0, (ld && inb) ? qb[4 * t + 3] : 0.0});
         }
         D2 gv = d2s(0.0), gw = d2s(0.0), hv = d2s(0.0), hw = d2s(0.0), rv = d2s(0.0), rw = d2s(0.0), dv = d2s(0.0), dw = d2s(0.0);
         D2 pv = d2s(0.0), pw = d2s(0.0);          // line-search trial point being consumed
@@ -707,7 +724,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
         bool posted = false;
-        bool akkt_last = false;                         // the last step's residual was below the tolerance: the AKKT residual will be needed again
+
         unsigned q_pass = 0;                            // n_pass at the last outer-iteration boundary (or at the start of this leg)
         bool parked = false, long_counted = false;      // (nmpc_solve_hyb.h: stepping aside at outer-iteration boundaries)
         int park_cls = POOL_LONG;
@@ -729,20 +746,18 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 
         for (;;) {
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
+            bool lb_batch = false;                     // this pass starts with the batch of inner products (f_back, f_begin)
             if (f_back) {
-                f_back = false;
                 if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }
                 lb_active = 0; lb_first = true;
+                NMPC2_LB_ZERO();
                 fbe_ok = false;
                 Lc *= 2.0; gamma /= 2.0;
                 sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 NMPC2_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
-                pair_sum(hdot2(rv, rw, rv, rw), hdot2(gv, gw, rv, rw), lane, nr2, gr);
-                norm_r = sqrt(nr2);
-                lip_it++;
-                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+                lb_batch = true;
             }
             // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1) | (tau/4, ls_n+2)
             if (f_trials) {
@@ -759,7 +774,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             if (f_fb) {
                 f_fb = false;
                 tau = 0.0;
-                ld4<H2_COLS>(Cgk, t, gv, gw);
+                ld4<H2_COLS>(Cgk, tc, gv, gw);
                 NMPC2_HALF_STEP(uv, uw);
                 xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
             }
@@ -775,40 +790,61 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 }
             }
             // ---------------------------------------------------------------- start of a PANOC step
+            if (f_begin) { rv = uv - hv; rw = uw - hw; lb_batch = true; }
+            // ---- the batch of inner products of this step (Gram-form L-BFGS: nmpc_solve_hyb.h has the design; here a quarter is ten stages --
+            // five entries of two planes -- and the oracle's qdot runs over 40 stages)
+            double gU = 0.0;
+            D2 gs1 = d2s(0.0), gs2 = d2s(0.0), gy1 = d2s(0.0), gy2 = d2s(0.0);
+            if (lb_batch) {
+                if (f_begin && iteration >= 1 && !lb_first) {
+                    D2 o1, o2, g1, g2;
+                    ld4<H2_COLS>(Cos, tc, o1, o2);
+                    ld4<H2_COLS>(Cog, tc, g1, g2);
+                    gs1 = uv - o1; gs2 = uw - o2; gy1 = rv - g1; gy2 = rw - g2;
+                }
+                if (t < H2_NS - 1 && h == 0) {
+                    st4<H2_NS>(Lnv, t, gs1, gs2); st4<H2_NS>(Lnv + 2 * H2_NS, t, gy1, gy2);
+                    st4<H2_NS>(Lnv + 4 * H2_NS, t, rv, rw); st4<H2_NS>(Lnv + 6 * H2_NS, t, gv, gw);
+                }
+                const lds_double2 *X1 = (c16 < MAXMEM ? LS + 2 * H2_NS * c16 : (c16 == 11 ? Lnv + 4 * H2_NS : Lnv)) + 5 * q4;
+                const lds_double2 *X2 = (c16 < MAXMEM ? LY + 2 * H2_NS * c16 : (c16 == 11 ? Lnv + 6 * H2_NS : Lnv + 2 * H2_NS)) + 5 * q4;
+                const lds_double2 *Z1 = (c16 < MAXMEM ? Lnv + 2 * H2_NS : (c16 == 10 ? Lnv : Lnv + 4 * H2_NS)) + 5 * q4;
+                const lds_double2 *Z2 = (c16 < MAXMEM ? Lnv + 4 * H2_NS : (c16 == 10 ? Lnv + 2 * H2_NS : Lnv + 4 * H2_NS)) + 5 * q4;
+                double V1 = 0.0, V2 = 0.0, V3 = 0.0, V4 = 0.0;
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {          // plane 0: the entry's first stage, plane 1: its second
+                        const dbl2 x1 = X1[pl * H2_NS + e], x2 = X2[pl * H2_NS + e], z1 = Z1[pl * H2_NS + e], z2 = Z2[pl * H2_NS + e];
+                        V1 = fma(x1.x, z1.x, V1); V1 = fma(x1.y, z1.y, V1);
+                        V2 = fma(x1.x, z2.x, V2); V2 = fma(x1.y, z2.y, V2);
+                        V3 = fma(x2.x, z1.x, V3); V3 = fma(x2.y, z1.y, V3);
+                        V4 = fma(x2.x, z2.x, V4); V4 = fma(x2.y, z2.y, V4);
+                    }
+                }
+                swap_rows(V1, V2);
+                double W12 = V1 + V2;
+                swap_rows(V3, V4);
+                double W34 = V3 + V4;
+                swap_halves(W12, W34);
+                gU = W12 + W34;
+                nr2 = lane_scalar(gU, 11);                       // <r, r>
+                gr = lane_scalar(gU, 32 + 11);                   // <g, r>
+                norm_r = sqrt(nr2);
+            }
+            if (f_back) {
+                f_back = false;
+                lip_it++;
+                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+            }
             if (f_begin) {
                 f_begin = false;
-                rv = uv - hv; rw = uw - hw;
-                // The reductions at the head of a step -- ||r||^2 | <g, r>, the curvature pair's <s, y> | <s, s>, the AKKT residual | <y, y> -- do not
-                // depend on each other; issued together their trees overlap (each is a chain of six dependent levels and this wave has its SIMD to
-                // itself).  What the step will need is predicted, wave-uniformly: the curvature pair unless the buffer has just been reset, the
-                // AKKT residual if the last step needed it.  The values are the ones the sequential code would form (same operands, same trees);
-                // whatever was not predicted is formed below as before.
-                const bool spec_lb = iteration >= 1 && !lb_first;
-                const bool spec_akkt = akkt_last && a.op.akkt_gradient == 1 && iteration >= 1;
-                D2 s1 = d2s(0.0), s2 = d2s(0.0), y1 = d2s(0.0), y2 = d2s(0.0), a1 = d2s(0.0), a2 = d2s(0.0);
-                double ys = 0.0, ss = 0.0, yy = 0.0, akkt2 = 0.0;
-                if (spec_akkt) { a1 = D2{rv.a / gamma, rv.b / gamma}; a2 = D2{rw.a / gamma, rw.b / gamma}; }
-                if (spec_lb) {
-                    D2 o1, o2, g1, g2;
-                    ld4<H2_COLS>(Cos, t, o1, o2);
-                    ld4<H2_COLS>(Cog, t, g1, g2);
-                    s1 = uv - o1; s2 = uw - o2; y1 = rv - g1; y2 = rw - g2;
-                    pair_sum(hdot2(rv, rw, rv, rw), hdot2(gv, gw, rv, rw), lane, nr2, gr);
-                    pair_sum(hdot2(s1, s2, y1, y2), hdot2(s1, s2, s1, s2), lane, ys, ss);
-                    pair_sum(hdot2(a1, a2, a1, a2), hdot2(y1, y2, y1, y2), lane, akkt2, yy);
-                } else {
-                    pair_sum(hdot2(rv, rw, rv, rw), hdot2(gv, gw, rv, rw), lane, nr2, gr);
-                    if (spec_akkt) akkt2 = group_sum<P>(hdot2(a1, a2, a1, a2), lane);
-                }
-                norm_r = sqrt(nr2);
                 bool exit_now = false;
-                akkt_last = __any(norm_r < a.op.tolerance);
-                if (akkt_last) {
+                if (__any(norm_r < a.op.tolerance)) {
                     if (a.op.akkt_gradient == 2) exit_now = true;
-                    else if (spec_akkt) exit_now = __any(sqrt(akkt2) < eps_nu);
                     else {
                         D2 q1, q2;
-                        ld4<H2_COLS>(Cq, t, q1, q2);
+                        ld4<H2_COLS>(Cq, tc, q1, q2);
                         const bool top = a.op.akkt_gradient == 1;
                         const D2 b1 = top ? (iteration >= 1 ? d2s(0.0) : gv) : gv - q1;
                         const D2 b2 = top ? (iteration >= 1 ? d2s(0.0) : gw) : gw - q2;
@@ -825,90 +861,81 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     lip_it = 0;
                     // ---- tentative L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
                     n_first = lb_first; n_head = lb_head; n_active = lb_active; n_H0 = H0; n_take_old = false;
+                    bool took = false;
                     if (lb_first) {
                         n_first = false; n_take_old = true;
                     } else {
+                        const double ss = lane_scalar(gU, 10), ys = lane_scalar(gU, 16 + 10);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
                         if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
                         if (__any(ok)) {
+                            took = true;
                             n_take_old = true;
-                            n_head = lb_head == 0 ? m - 1 : lb_head - 1;
-                            if (in && h == 0) { st4<H2_NS>(LS + 2 * H2_NS * (n_head), t, s1, s2); st4<H2_NS>(LY + 2 * H2_NS * (n_head), t, y1, y2); }
+                            n_head = lb_head == 0 ? MAXMEM - 1 : lb_head - 1;      // (the ring always turns over its ten slots)
+                            if (in && h == 0) { st4<H2_NS>(LS + 2 * H2_NS * (n_head), t, gs1, gs2); st4<H2_NS>(LY + 2 * H2_NS * (n_head), t, gy1, gy2); }
                             if (lane == 0) Lrho[n_head] = 1.0 / ys;
+                            const double yy = lane_scalar(gU, 48 + 10);
                             n_H0 = ys / yy;
                             if (n_active < m) n_active++;
-                            NMPC_WAVE_SYNC();
+                            if (c16 < MAXMEM && q4 < 3) {
+                                const bool dg = c16 == n_head;
+                                lds_double *wa = q4 == 0 ? Lgsy + c16 * MAXMEM + n_head : (q4 == 1 ? Lgsy + n_head * MAXMEM + c16 : Lgyy + c16 * MAXMEM + n_head);
+                                const double wv = q4 == 1 ? 0.0 : (dg ? (q4 == 0 ? 0.0 : yy) : gU);
+                                *wa = wv;
+                                if (q4 == 2) Lgyy[n_head * MAXMEM + c16] = wv;
+                            }
+                            if (m < MAXMEM) {      // a shorter memory: the pair that has just reached age m leaves, its slot goes back to zeros
+                                const int ev = n_head + m >= MAXMEM ? n_head + m - MAXMEM : n_head + m;
+                                if (t < H2_NS && h == 0) { st4<H2_NS>(LS + 2 * H2_NS * (ev), t, d2s(0.0), d2s(0.0)); st4<H2_NS>(LY + 2 * H2_NS * (ev), t, d2s(0.0), d2s(0.0)); }
+                                if (lane == 0) Lrho[ev] = 0.0;
+                                if (c16 < MAXMEM && q4 < 2) {
+                                    (q4 == 0 ? Lgsy : Lgyy)[c16 * MAXMEM + ev] = 0.0;
+                                    (q4 == 0 ? Lgsy : Lgyy)[ev * MAXMEM + c16] = 0.0;
+                                }
+                            }
                         }
                     }
-                    // ---- d = H r, two-loop recursion over the tentative buffer (each trip fetches the NEXT pair first) ----
+                    // ---- d = H r over the tentative buffer: the two recurrences in lanes 0..9 of every row, the direction updated along ----
                     dv = rv; dw = rw;
-                    if (n_active == MAXMEM && m == MAXMEM) {
-                        // full buffer (the steady state): branch-free, all pairs addressed from the head, no register rotation
-                        double alpha[MAXMEM];
-#pragma unroll
-                        for (int k = 0; k < MAXMEM; ++k) {
-                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
-                            D2 s1_, s2_, y1_, y2_;
-                            ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, s1_, s2_);
-                            ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, y1_, y2_);
-                            const double al = Lrho[slot] * group_sum<P>(hdot2(s1_, s2_, dv, dw), lane);
-                            alpha[k] = al;
-                            dv = fma2(-al, y1_, dv); dw = fma2(-al, y2_, dw);
-                        }
+                    if (n_active > 0) {
+                        const int pk_ = c16 < MAXMEM ? (n_head + c16 >= MAXMEM ? n_head + c16 - MAXMEM : n_head + c16) : MAXMEM - 1;
+                        const int pkrow = pk_ * MAXMEM;
+                        double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
+                        if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }
+                        const double rho_k = Lrho[pk_];
+#define NMPC2_GRAM_FWD(J)                                                                          \
+                        do {                                                                       \
+                            const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J); \
+                            const double gs_ = Lgsy[pkrow + pj_], gy_ = Lgyy[pkrow + pj_];         \
+                            D2 y1_, y2_;                                                           \
+                            ld4<H2_NS>(LY + 2 * H2_NS * (pj_), tt, y1_, y2_);                      \
+                            const double al_ = rho_k * ga1;                                        \
+                            ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                              \
+                            const double bc_ = row_bcast_lane<(J)>(al_);                           \
+                            ga2 = fma(-bc_, gy_, ga2);                                             \
+                            dv = fma2(-bc_, y1_, dv); dw = fma2(-bc_, y2_, dw);                    \
+                        } while (0)
+#define NMPC2_GRAM_BWD(J)                                                                          \
+                        do {                                                                       \
+                            const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J); \
+                            const double gr_ = Lgsy[pj_ * MAXMEM + pk_];                           \
+                            D2 s1_, s2_;                                                           \
+                            ld4<H2_NS>(LS + 2 * H2_NS * (pj_), tt, s1_, s2_);                      \
+                            const double be_ = rho_k * ga2;                                        \
+                            const double ab_ = alv - be_;                                          \
+                            ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                               \
+                            const double bc_ = row_bcast_lane<(J)>(ab_);                           \
+                            dv = fma2(bc_, s1_, dv); dw = fma2(bc_, s2_, dw);                      \
+                        } while (0)
+                        NMPC2_GRAM_FWD(0); NMPC2_GRAM_FWD(1); NMPC2_GRAM_FWD(2); NMPC2_GRAM_FWD(3); NMPC2_GRAM_FWD(4);
+                        NMPC2_GRAM_FWD(5); NMPC2_GRAM_FWD(6); NMPC2_GRAM_FWD(7); NMPC2_GRAM_FWD(8); NMPC2_GRAM_FWD(9);
+                        const double alv = rho_k * ga1;
+                        ga2 = n_H0 * ga2;
                         dv = n_H0 * dv; dw = n_H0 * dw;
-#pragma unroll
-                        for (int k = MAXMEM - 1; k >= 0; --k) {
-                            int slot = n_head + k; if (slot >= MAXMEM) slot -= MAXMEM;
-                            D2 s1_, s2_, y1_, y2_;
-                            ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, s1_, s2_);
-                            ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, y1_, y2_);
-                            const double be = Lrho[slot] * group_sum<P>(hdot2(y1_, y2_, dv, dw), lane);
-                            const double ab = alpha[k] - be;
-                            dv = fma2(ab, s1_, dv); dw = fma2(ab, s2_, dw);
-                        }
-                    } else if (n_active > 0) {
-                        double alpha[MAXMEM];
-                        int slot = n_head;
-                        D2 sc1, sc2, yc1, yc2;
-                        ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, sc1, sc2);
-                        ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, yc1, yc2);
-                        double rc_ = Lrho[slot];
-#pragma unroll
-                        for (int k = 0; k < MAXMEM; ++k) {
-                            alpha[k] = 0.0;
-                            if (k < n_active) {
-                                D2 sn1 = d2s(0.0), sn2 = d2s(0.0), yn1 = d2s(0.0), yn2 = d2s(0.0);
-                                double rn_ = 0.0;
-                                if (k + 1 < n_active) {
-                                    slot = slot + 1 == m ? 0 : slot + 1;
-                                    ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, sn1, sn2);
-                                    ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, yn1, yn2);
-                                    rn_ = Lrho[slot];
-                                }
-                                const double al = rc_ * group_sum<P>(hdot2(sc1, sc2, dv, dw), lane);
-                                alpha[k] = al;
-                                dv = fma2(-al, yc1, dv); dw = fma2(-al, yc2, dw);
-                                if (k + 1 < n_active) { sc1 = sn1; sc2 = sn2; yc1 = yn1; yc2 = yn2; rc_ = rn_; }
-                            }
-                        }
-                        dv = n_H0 * dv; dw = n_H0 * dw;
-#pragma unroll
-                        for (int k = MAXMEM - 1; k >= 0; --k) {
-                            if (k < n_active) {
-                                D2 sn1 = d2s(0.0), sn2 = d2s(0.0), yn1 = d2s(0.0), yn2 = d2s(0.0);
-                                double rn_ = 0.0;
-                                if (k > 0) {
-                                    slot = slot == 0 ? m - 1 : slot - 1;
-                                    ld4<H2_NS>(LS + 2 * H2_NS * (slot), tt, sn1, sn2);
-                                    ld4<H2_NS>(LY + 2 * H2_NS * (slot), tt, yn1, yn2);
-                                    rn_ = Lrho[slot];
-                                }
-                                const double be = rc_ * group_sum<P>(hdot2(yc1, yc2, dv, dw), lane);
-                                const double ab = alpha[k] - be;
-                                dv = fma2(ab, sc1, dv); dw = fma2(ab, sc2, dw);
-                                if (k > 0) { sc1 = sn1; sc2 = sn2; yc1 = yn1; yc2 = yn2; rc_ = rn_; }
-                            }
-                        }
+                        NMPC2_GRAM_BWD(9); NMPC2_GRAM_BWD(8); NMPC2_GRAM_BWD(7); NMPC2_GRAM_BWD(6); NMPC2_GRAM_BWD(5);
+                        NMPC2_GRAM_BWD(4); NMPC2_GRAM_BWD(3); NMPC2_GRAM_BWD(2); NMPC2_GRAM_BWD(1); NMPC2_GRAM_BWD(0);
+#undef NMPC2_GRAM_FWD
+#undef NMPC2_GRAM_BWD
                     }
                     if (!fbe_ok) { fbe_u = NMPC2_FBE(uv, uw); fbe_ok = true; }
                     rhs_ls = fbe_u - sigma * nr2;
@@ -952,6 +979,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 f_start = false;
                 { D2 y1, y2; ld4<H2_COLS>(Cy, te, y1, y2); st4<H2_COLS>(Cy, te, clamp2(y1, -1e12, 1e12), clamp2(y2, -1e12, 1e12)); }      // y <- Pi_Y(y)
                 lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                NMPC2_LB_ZERO();
                 const D2 h1 = D2{EPSILON_LIPSCHITZ * uv.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.a : DELTA_LIPSCHITZ,
                                  EPSILON_LIPSCHITZ * uv.b > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.b : DELTA_LIPSCHITZ};
                 const D2 h2 = D2{EPSILON_LIPSCHITZ * uw.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw.a : DELTA_LIPSCHITZ,
@@ -989,7 +1017,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 #define NMPC2_TAKE_TRIAL_(PSI, FETCH)                                                  \
             do {                                                                       \
                 n_grad++;                                                              \
-                st4<H2_COLS>(Cq, t, gv, gw);                     /* cache_previous_gradient */     \
+                st4<H2_COLS>(Cq, tc, gv, gw);                     /* cache_previous_gradient */     \
                 cost = (PSI);                                                          \
                 FETCH;                                                                 \
                 const double omt_ = 1.0 - tau;                                         \
@@ -1026,7 +1054,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     f_back = true;
                 } else {
                     if (state == D_LIP) {
-                        lb_first = false; st4<H2_COLS>(Cos, t, uv, uw); st4<H2_COLS>(Cog, t, rv, rw);
+                        lb_first = false; st4<H2_COLS>(Cos, tc, uv, uw); st4<H2_COLS>(Cog, tc, rv, rw);
                         if (iteration == 0) {
                             n_grad++;
                             uv = hv; uw = hw;
@@ -1039,13 +1067,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             dv = rv; dw = rw;                            // empty buffer: d = r
                             rhs_ls = NMPC2_FBE(uv, uw) - sigma * nr2;
                             tau = 1.0; ls_n = 0;
-                            if (a.op.ls_failure == 1) st4<H2_COLS>(Cgk, t, gv, gw);
+                            if (a.op.ls_failure == 1) st4<H2_COLS>(Cgk, tc, gv, gw);
                             f_trials = true;
                         }
                     } else {
                         lb_first = n_first; lb_head = n_head; lb_active = n_active; H0 = n_H0;      // commit
-                        if (n_take_old) { st4<H2_COLS>(Cos, t, uv, uw); st4<H2_COLS>(Cog, t, rv, rw); }
-                        if (a.op.ls_failure == 1) st4<H2_COLS>(Cgk, t, gv, gw);
+                        if (n_take_old) { st4<H2_COLS>(Cos, tc, uv, uw); st4<H2_COLS>(Cog, tc, rv, rw); }
+                        if (a.op.ls_failure == 1) st4<H2_COLS>(Cgk, tc, gv, gw);
                         NMPC2_TAKE_TRIAL(psiB, 1);                       // tau = 1
                         if (rejected) NMPC2_TAKE_TRIAL(psiC, 2);         // tau = 1/2
                         if (posted) {
@@ -1091,8 +1119,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                                     n_grad += (unsigned)jstop + 1u; ls_n += jstop;
                                     tau *= jstop == 0 ? 1.0 : (jstop == 1 ? 0.5 : 0.25);
                                     if (jstop > 0) prev_ag = ag + 2 * ((jstop - 1) * H2_ENT);
-                                    if (prev_ag) { D2 p1, p2; NMPC2_LOAD_GRAD(prev_ag, p1, p2); st4<H2_COLS>(Cq, t, p1, p2); }
-                                    else st4<H2_COLS>(Cq, t, gv, gw);
+                                    if (prev_ag) { D2 p1, p2; NMPC2_LOAD_GRAD(prev_ag, p1, p2); st4<H2_COLS>(Cq, tc, p1, p2); }
+                                    else st4<H2_COLS>(Cq, tc, gv, gw);
                                     cost = sc_[jstop];
                                     NMPC2_LOAD_GRAD(ag + 2 * (jstop * H2_ENT), gv, gw);
                                     const double omt_ = 1.0 - tau;
@@ -1190,11 +1218,11 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             NMPC_WAVE_SYNC();          // (the multipliers were stored by the evaluation lanes, the state lanes read them)
             if (in && h == 0) {
                 D2 q1, q2;
-                ld4<H2_COLS>(Cq, t, q1, q2);
+                ld4<H2_COLS>(Cq, tc, q1, q2);
                 po[4 * t] = uv.a; po[4 * t + 1] = uw.a; po[4 * N + 4 * t] = q1.a; po[4 * N + 4 * t + 1] = q2.a;
                 if (inb) { po[4 * t + 2] = uv.b; po[4 * t + 3] = uw.b; po[4 * N + 4 * t + 2] = q1.b; po[4 * N + 4 * t + 3] = q2.b; }
                 D2 y1, y2;
-                ld4<H2_COLS>(Cy, t, y1, y2);
+                ld4<H2_COLS>(Cy, tc, y1, y2);
                 po[2 * N + 2 * t] = y1.a; po[3 * N + 2 * t] = y2.a;
                 if (inb) { po[2 * N + 2 * t + 1] = y1.b; po[3 * N + 2 * t + 1] = y2.b; }
             }
@@ -1218,7 +1246,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             if (inb) { uo[4 * t + 2] = uv.b; uo[4 * t + 3] = uw.b; }
             if (a.y_out) {
                 D2 y1, y2;
-                ld4<H2_COLS>(Cyp, t, y1, y2);
+                ld4<H2_COLS>(Cyp, tc, y1, y2);
                 double *yo = a.y_out + (size_t)inst * a.n1;
                 yo[2 * t] = y1.a; yo[N + 2 * t] = y2.a;
                 if (inb) { yo[2 * t + 1] = y1.b; yo[N + 2 * t + 1] = y2.b; }

@@ -196,15 +196,16 @@ static double hdot(const hvec *a, const hvec *b, int P)
     return tree_sum_p(t, P);
 }
 
-/* The inner product of the Gram-form L-BFGS (N <= 20): the 20 (zero padded) stages in four quarters of five, each quarter one
+/* The inner product of the Gram-form L-BFGS: the nst (20 or 40, zero padded) stages in four quarters, each quarter one
  * sequential fma chain over (v_t, w_t) from +0.0, the quarters combined as (q0 + q1) + (q2 + q3).  What a wavefront computes when
  * lane (vector, quarter) runs its chain and the four wave rows are then added with two permlane swaps (nmpc_solve_hyb.h). */
-static double qdot(const hvec *a, const hvec *b)
+static double qdot(const hvec *a, const hvec *b, int nst)
 {
     double q[4];
+    const int n4 = nst / 4;
     for (int i = 0; i < 4; ++i) {
         double acc = 0.0;
-        for (int t = 5 * i; t < 5 * i + 5; ++t) { acc = fma(a->v[t], b->v[t], acc); acc = fma(a->w[t], b->w[t], acc); }
+        for (int t = n4 * i; t < n4 * i + n4; ++t) { acc = fma(a->v[t], b->v[t], acc); acc = fma(a->w[t], b->w[t], acc); }
         q[i] = acc;
     }
     return (q[0] + q[1]) + (q[2] + q[3]);
@@ -539,10 +540,12 @@ int orc_eval(const orc_problem *pb, const double *p, const double *u, double c, 
 #define LBFGS_CBFGS_EPSILON 1e-8     /* with cbfgs alpha = 1 */
 
 #define GRAM_M 10      /* pairs the Gram form carries (the hybrid kernel's ring): ages >= m, and inactive ages, are exactly zero */
-#define GRAM_NST 20    /* stages the quarter dot runs over (N <= 20, zero padded) */
+/* stages the quarter dot runs over (zero padded): 20 for N <= 20 (nmpc_solve_hyb.h), 40 for 32 < N <= 40 (nmpc_solve_hyb2.h) */
+#define GRAM_NST(N) ((N) <= 20 ? 20 : 40)
+#define GRAM_SERVES(N) ((N) <= 20 || ((N) > 32 && (N) <= 40))
 typedef struct {
     int m, active, first_old;
-    int gram;                      /* 1: the Gram form below (N <= 20: what nmpc_solve_hyb.h computes); 0: the two-loop recursion */
+    int gram;                      /* > 0: the Gram form below, over this many stages (what nmpc_solve_hyb.h / nmpc_solve_hyb2.h compute); 0: the two-loop recursion */
     hvec S[MAXMEM], Y[MAXMEM];     /* index 0 = newest */
     double rho[MAXMEM];
     double H0;
@@ -584,7 +587,7 @@ static void grad_and_half_step(const inst_t *I, panoc_t *c, const hvec *x)
 static void compute_fpr(const inst_t *I, panoc_t *c, const hvec *u)
 {
     for (int t = 0; t < I->P; ++t) { c->r.v[t] = u->v[t] - c->uh.v[t]; c->r.w[t] = u->w[t] - c->uh.w[t]; }
-    c->nr2 = c->lb.gram ? qdot(&c->r, &c->r) : hdot(&c->r, &c->r, I->P);
+    c->nr2 = c->lb.gram ? qdot(&c->r, &c->r, c->lb.gram) : hdot(&c->r, &c->r, I->P);
     c->norm_r = sqrt(c->nr2);
 }
 
@@ -608,7 +611,7 @@ static void lbfgs_update(const inst_t *I, lbfgs_t *lb, const hvec *r, const hvec
         s.v[t] = u->v[t] - lb->old_s.v[t]; s.w[t] = u->w[t] - lb->old_s.w[t];
         y.v[t] = r->v[t] - lb->old_g.v[t]; y.w[t] = r->w[t] - lb->old_g.w[t];
     }
-    const double ys = lb->gram ? qdot(&s, &y) : hdot(&s, &y, P), ss = lb->gram ? qdot(&s, &s) : hdot(&s, &s, P);
+    const double ys = lb->gram ? qdot(&s, &y, lb->gram) : hdot(&s, &y, P), ss = lb->gram ? qdot(&s, &s, lb->gram) : hdot(&s, &s, P);
     if (ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON) return;
     if (!(ys / ss > LBFGS_CBFGS_EPSILON * norm_r)) return;
     lb->old_s = *u;
@@ -623,12 +626,12 @@ static void lbfgs_update(const inst_t *I, lbfgs_t *lb, const hvec *r, const hvec
         for (int a = lb->m - 1; a > 0; --a)
             for (int b = lb->m - 1; b > 0; --b) { lb->SY[a][b] = lb->SY[a - 1][b - 1]; lb->YY[a][b] = lb->YY[a - 1][b - 1]; }
         for (int a = 1; a < lb->m; ++a) {
-            lb->SY[a][0] = qdot(&lb->S[a], &y);
+            lb->SY[a][0] = qdot(&lb->S[a], &y, lb->gram);
             lb->SY[0][a] = 0.0;
-            lb->YY[a][0] = lb->YY[0][a] = qdot(&lb->Y[a], &y);
+            lb->YY[a][0] = lb->YY[0][a] = qdot(&lb->Y[a], &y, lb->gram);
         }
         lb->SY[0][0] = 0.0;
-        lb->YY[0][0] = qdot(&y, &y);
+        lb->YY[0][0] = qdot(&y, &y, lb->gram);
         lb->H0 = ys / lb->YY[0][0];
     } else
     lb->H0 = ys / hdot(&y, &y, P);
@@ -647,7 +650,7 @@ static void lbfgs_apply_gram(const inst_t *I, const lbfgs_t *lb, hvec *d)
     double a1[GRAM_M], a2[GRAM_M], alv[GRAM_M];
     if (lb->active == 0) return;
     const hvec r = *d;
-    for (int k = 0; k < GRAM_M; ++k) { a1[k] = qdot(&lb->S[k], &r); a2[k] = qdot(&lb->Y[k], &r); }
+    for (int k = 0; k < GRAM_M; ++k) { a1[k] = qdot(&lb->S[k], &r, lb->gram); a2[k] = qdot(&lb->Y[k], &r, lb->gram); }
     for (int j = 0; j < GRAM_M; ++j) {
         const double al = lb->rho[j] * a1[j];
         for (int k = 0; k < GRAM_M; ++k) { a1[k] = fma(-al, lb->SY[k][j], a1[k]); a2[k] = fma(-al, lb->YY[k][j], a2[k]); }
@@ -767,7 +770,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         double cost_uh = o->psi;
         int n_back = 0, n_trials = 0;
         for (int it = 0; it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && c->L < MAX_LIPSCHITZ_CONSTANT; ++it) {
-            const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - (c->lb.gram ? qdot(&c->g, &c->r) : hdot(&c->g, &c->r, P))
+            const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - (c->lb.gram ? qdot(&c->g, &c->r, c->lb.gram) : hdot(&c->g, &c->r, P))
                              + (GAMMA_L_COEFF / (2.0 * c->gamma)) * c->nr2;
             if (!(cost_uh > rhs)) break;
             lbfgs_reset(&c->lb);
@@ -868,9 +871,9 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
     prepare(pb, p, I);
     const int P = I->P, n2 = pb->nobs + pb->ndyn;
     pc->lb.m = opts->lbfgs_memory;
-    /* the L-BFGS arithmetic follows the kernel that solves this horizon: Gram form for N <= 20 (nmpc_solve_hyb.h), the two-loop
-     * recursion otherwise; opts->lbfgs_form = 1 forces the two-loop recursion (tests compare the two) */
-    pc->lb.gram = N <= GRAM_NST && opts->lbfgs_memory <= GRAM_M && opts->lbfgs_form != 1;
+    /* the L-BFGS arithmetic follows the kernel that solves this horizon: Gram form for N <= 20 (nmpc_solve_hyb.h) and 32 < N <= 40
+     * (nmpc_solve_hyb2.h), the two-loop recursion otherwise; opts->lbfgs_form = 1 forces the two-loop recursion (tests compare the two) */
+    pc->lb.gram = (GRAM_SERVES(N) && opts->lbfgs_memory <= GRAM_M && opts->lbfgs_form != 1) ? GRAM_NST(N) : 0;
     hvec u, y, yplus;
     load_hvec(&u, u_io, N, 1);
     load_hvec(&y, y0, N, 0);
