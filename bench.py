@@ -100,6 +100,7 @@ def build_report(kernel_name):
     res = {k: v for k, v in info.get("resources", {}).items() if short in k and (not tmpl or tmpl in k or tmpl.isdigit())}
     chk = info.get("codegen_check", {})
     return {"flags": " ".join(info.get("flags") or []), "source_hash": info.get("source_hash"), "stale": bool(info.get("stale")),
+            "experiments": bool(_lib.load_library().nmpc_experiments_build()),      # False: the shipped library reads no environment knob
             "codegen_check": {k: chk.get(k) for k in ("ok", "sched_changed", "sched_latent", "exec_hits", "exec_restores")},
             "kernel_resources": next(iter(res.values()), None), "dynamic_lds_note": "LDS is dynamic: one slice per wave, DESIGN.md section 3"}
 
@@ -119,6 +120,23 @@ def pmc_traffic(kernel_name, config, B, routes):
         for e in entries if isinstance(entries, list) else [entries]:
             if all(e.get(k) == v for k, v in want.items()):
                 return float(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def scan_shares(kernel_name, config):
+    """Share of the evaluations in which the exact certificates of eval_psi fell back to the full cross-track scan / ran the obstacle
+    activity scan (counters of a -DNMPC_WIN_STATS build, scripts/win_stats.py -> profiles/*/scan_shares.json), keyed like the PMC traffic
+    by kernel + source hash + config; None if not measured for these sources."""
+    import glob
+    from mpc_trajectory_generator_amd import _lib
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "scan_shares.json")), reverse=True):
+        try:
+            entries = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in entries:
+            if e.get("kernel") == kernel_name and e.get("config") == config and e.get("source_hash") == _lib.source_hash():
+                return e, os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -329,6 +347,16 @@ def main():
                      + s["num_inner_iterations"].astype(np.float64).sum() * f_iter)
 
     flops = flops_of(st)
+    # what the ALUs execute of that: the windowed cross-track search measures three segments instead of N - 1, the obstacle certificate
+    # skips the activity scan -- both exact, both fall back to the full work in a measured share of the evaluations
+    shares, shares_src = scan_shares(solver.kernel_name, args.config)
+    executed_frac = None
+    if shares:
+        N_, No_, Nd_ = cfg.N_hor, cfg.Nobs, cfg.Ndynobs
+        sw, so = shares["window_full_scan_share"], shares["obstacle_scan_share"]
+        f_fwd_x = N_ * (28 + (7 * No_ + 15 * Nd_) * so + 21 * ((N_ - 1) * sw + 3 * (1 - sw))) + 14 * N_
+        n_ev = float(st["num_cost_evals"].astype(np.float64).sum() + st["num_grad_evals"].astype(np.float64).sum())
+        executed_frac = (flops - n_ev * (f_fwd - f_fwd_x)) / flops
     bytes_alg = float(B * (8 * (cfg.n_p + 2 * cfg.n_u + cfg.n1) + 72))
     conv = st["exit_status"] == 0
     stats = np.array([st["num_inner_iterations"].sum(), st["num_outer_iterations"].sum(), conv.sum(), B,
@@ -468,7 +496,14 @@ def main():
                               "mean_instance_ms": float(st["solve_time_ms"].mean())},
         # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s);
         # the kernel issues no MFMA -- "bound_detail" says what actually limits it
-        "roofline": {"bound": "mfma", "bound_detail": "valu_f64", "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
+        "roofline": {"bound": "valu_f64", "bound_class": "mfma (the compute-side roofline of the bench contract; the kernel issues no MFMA)",
+                     "model": "algorithmic flops of the sequential method from the solver's own counters: F_fwd = N(28 + 7 Nobs + 15 Ndyn + 21 (N - 1)) + 14 N "
+                              "per evaluation (SURVEY.md App. G), + the as-implemented adjoint N(88 + 9 Nobs + 16 Ndyn) per gradient (NOT the survey's 4 x F_cost guess), "
+                              "+ 70 n_u per PANOC iteration; fma = 2",
+                     "executed_frac": executed_frac, "executed_frac_source": shares_src,
+                     "executed_frac_note": "share of the credited flops the ALUs execute: the exact windowed cross-track search and the exact obstacle "
+                                           "certificate skip the rest (null: certificates not counted for these sources)",
+                     "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
                      "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)", "traffic_source": traffic_src,
                      "kernel": solver.kernel_name, "kernel_ms": kern_ms,

@@ -145,6 +145,10 @@ void nmpc_free(nmpc_handle *h);
 int nmpc_ping(const nmpc_handle *h);
 const char *nmpc_last_error(const nmpc_handle *h);
 int nmpc_abi_version(void);
+/* 0 for the shipped library: it reads no environment variable and has no tuning knob beyond nmpc_opts.  1 for the experiments build
+ * (-DNMPC_EXPERIMENTS, csrc/variants/libnmpc_experiments.so), which tests and measurement scripts use to force alternative kernels and
+ * scheduling policies and check that they give the same bits.  (The interface being replaced has no knobs: src/path_generator.py:218-222.) */
+int nmpc_experiments_build(void);
 /* Diagnostic: the solve kernel this handle launches (the name a rocprofv3 kernel trace shows). */
 const char *nmpc_kernel_name(const nmpc_handle *h);
 

@@ -19,7 +19,7 @@ BUILD_INFO = os.path.join(_CSRC, "build_info.json")      # written by build_libr
 # every symbol include/nmpc_solver.h declares
 SYMBOLS = (
     "nmpc_default_opts", "nmpc_n_u", "nmpc_n_p", "nmpc_n1", "nmpc_n2", "nmpc_new", "nmpc_free",
-    "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_kernel_name", "nmpc_solve_batch_device",
+    "nmpc_ping", "nmpc_last_error", "nmpc_abi_version", "nmpc_experiments_build", "nmpc_kernel_name", "nmpc_solve_batch_device",
     "nmpc_solve_batch_host", "nmpc_last_batch_ms", "nmpc_eval_batch_device", "nmpc_eval_batch_host",
     "nmpc_test_sincos_host", "nmpc_test_divsqrt_host",
     "nmpc_loop_new", "nmpc_loop_free", "nmpc_loop_step", "nmpc_loop_read", "nmpc_loop_params",
@@ -120,13 +120,15 @@ def build_library(force: bool = False) -> str:
                 res = codegen_check.verify()
                 info = {"source_hash": source_hash(), "flags": res.get("flags"), "codegen_check": {k: v for k, v in res.items() if k != "resources"},
                         "resources": res.get("resources", {})}
-                with open(BUILD_INFO, "w") as fh:
-                    json.dump(info, fh, indent=1)
                 if not res["ok"]:
                     os.remove(os.path.join(_CSRC, tmp))
+                    with open(BUILD_INFO + ".refused", "w") as fh:      # (build_info.json keeps describing the library that is in place)
+                        json.dump(info, fh, indent=1)
                     raise RuntimeError("libnmpc_hip.so REFUSED: the compiler generated wrong code for these flags (codegen_check): " +
                                        json.dumps(info["codegen_check"])[:3000])
                 os.replace(os.path.join(_CSRC, tmp), LIB_PATH)
+                with open(BUILD_INFO, "w") as fh:
+                    json.dump(info, fh, indent=1)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
@@ -136,6 +138,9 @@ def build_library(force: bool = False) -> str:
 # whose results depend on the schedule has a defect (or the compiler has: codegen_check.py), and the shipped strategy may only be hiding it.
 STRATEGIES = {"default": [], "max-memory-clause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
               "max-ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# The shipped library reads no environment variable.  The knobs tests and scripts need (force the run-time-shape kernel, team modes, scheduler
+# and migration settings, culling radius) exist only in this variant: the shipped sources and scheduler flags + -DNMPC_EXPERIMENTS.
+EXPERIMENTS = "experiments"
 
 
 def variant_path(name: str) -> str:
@@ -145,7 +150,9 @@ def variant_path(name: str) -> str:
 def build_variant(name: str, force: bool = False) -> dict:
     """Build csrc/variants/libnmpc_<name>.so with strategy `name` and run the code-generation check on it; -> that check's result."""
     from . import codegen_check
-    flags = STRATEGIES[name]
+    import fcntl
+    experiments = name == EXPERIMENTS
+    flags = None if experiments else STRATEGIES[name]
     out, meta = variant_path(name), variant_path(name)[:-3] + ".json"
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if os.path.exists(out) and os.path.exists(meta) and not force:      # fresh = built from these very sources (content, not time stamps)
@@ -153,11 +160,23 @@ def build_variant(name: str, force: bool = False) -> dict:
             res = json.load(fh)
         if res.get("source_hash") == source_hash():
             return res
-    r = subprocess.run(["make", "-C", _CSRC, "-B", os.path.relpath(out, _CSRC), f"OUT={os.path.relpath(out, _CSRC)}", "SCHED=" + " ".join(flags)],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"building {out} failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
-    res = codegen_check.verify(flags)
+    with open(os.path.join(_CSRC, ".build.lock"), "w") as lock:      # (several test processes may ask for the same variant)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(out) and os.path.exists(meta) and not force:
+                with open(meta) as fh:
+                    res = json.load(fh)
+                if res.get("source_hash") == source_hash():
+                    return res
+            tmp = os.path.relpath(out, _CSRC) + f".tmp{os.getpid()}"
+            cmd = ["make", "-C", _CSRC, "-B", tmp, f"OUT={tmp}"] + (["EXTRA=-DNMPC_EXPERIMENTS"] if experiments else ["SCHED=" + " ".join(flags)])
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"building {out} failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+            os.replace(os.path.join(_CSRC, tmp), out)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    res = codegen_check.verify(flags) if not experiments else dict(build_info().get("codegen_check", {"ok": True}))      # (experiments: the shipped kernels' machine code)
     res.pop("resources", None)
     res["source_hash"] = source_hash()
     with open(meta, "w") as fh:
@@ -176,15 +195,28 @@ def build_info() -> dict:
 
 
 _lib = None
+_lib_experiments = None
 
 
-def load_library() -> C.CDLL:
-    """Load (building if needed) the HIP library; raises if that is impossible."""
-    global _lib
+def load_library(experiments: bool = False) -> C.CDLL:
+    """Load (building if needed) the HIP library; raises if that is impossible.  experiments=True: the variant with the environment knobs
+    (tests and scripts only; the product never asks for it)."""
+    global _lib, _lib_experiments
+    if experiments:
+        if _lib_experiments is None:
+            build_library()
+            build_variant(EXPERIMENTS)
+            _lib_experiments = _bind(C.CDLL(variant_path(EXPERIMENTS)), variant_path(EXPERIMENTS))
+            assert _lib_experiments.nmpc_experiments_build() == 1
+        return _lib_experiments
     if _lib is not None:
         return _lib
     path = os.environ.get("NMPC_LIB_PATH") or build_library()      # (NMPC_LIB_PATH: instrumented builds, scripts/ only)
-    lib = C.CDLL(path)
+    _lib = _bind(C.CDLL(path), path)
+    return _lib
+
+
+def _bind(lib: C.CDLL, path: str) -> C.CDLL:
     lib.nmpc_abi_version.restype = C.c_int
     if lib.nmpc_abi_version() != EXPECTED_ABI:      # a stale / foreign .so would silently misread nmpc_opts
         raise RuntimeError(f"{path}: ABI version {lib.nmpc_abi_version()}, this package expects {EXPECTED_ABI} "
@@ -219,7 +251,7 @@ def load_library() -> C.CDLL:
     lib.nmpc_loop_read.argtypes = [vp, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), vp]
     lib.nmpc_loop_params.argtypes = [vp, dp, dp, dp]
     lib.nmpc_loop_trajectory.argtypes = [vp, dp, C.c_int]
-    _lib = lib
+    lib.nmpc_experiments_build.restype = C.c_int
     return lib
 
 

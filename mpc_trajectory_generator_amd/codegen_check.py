@@ -192,9 +192,10 @@ def check_exec_restores(text):
 # ------------------------------------------------------------------------------------------------- driver
 def makefile_flags():
     """the code-generation flags csrc/Makefile builds with (its scheduler strategy)"""
-    mk = open(os.path.join(CSRC, "Makefile")).read()
-    m = re.search(r"-amdgpu-sched-strategy=([\w-]+)", mk)
-    return ["-mllvm", f"-amdgpu-sched-strategy={m.group(1)}"] if m else []
+    r = subprocess.run(["make", "-s", "-C", CSRC, "print-sched"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("make print-sched failed: " + r.stderr[-500:])
+    return r.stdout.split()
 
 
 def kernel_resources(asm_text):

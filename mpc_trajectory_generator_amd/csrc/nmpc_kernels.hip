@@ -1266,6 +1266,14 @@ int nmpc_n1(const nmpc_problem *pb) { return 2 * pb->N; }
 int nmpc_n2(const nmpc_problem *pb) { return pb->nobs + pb->ndyn; }
 int nmpc_n_p(const nmpc_problem *pb) { return nmpc::NZ + pb->N + 3 * pb->nobs + 5 * pb->ndyn * pb->N + 3 * pb->N; }
 int nmpc_abi_version(void) { return NMPC_ABI_VERSION; }
+int nmpc_experiments_build(void)
+{
+#ifdef NMPC_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 static int fail(nmpc_handle *h, int code, const char *what, hipError_t e = hipSuccess)
 {
@@ -1302,40 +1310,41 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true; h->last_ms = 0.0;
     h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : (pb->N <= 40 ? 40 : 64));
-    if (const char *env = getenv("NMPC_LAYOUT")) {             // experiments / cross-checks: force the two-point layout
-        if (!strcmp(env, "dual") && pb->N <= 32) h->P = 32;
-    }
     h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
     h->shape_nobs50 = pb->N == nmpc::ShapeNobs50::N && pb->nobs == nmpc::ShapeNobs50::NOBS &&
                       pb->ndyn == nmpc::ShapeNobs50::NDYN;
     h->shape_n40 = pb->N == nmpc::ShapeN40::N && pb->nobs == nmpc::ShapeN40::NOBS && pb->ndyn == nmpc::ShapeN40::NDYN;
-    if (const char *env = getenv("NMPC_SHAPE")) {              // experiments: force the run-time-shape kernel
+#ifdef NMPC_EXPERIMENTS      // (the experiments build, csrc/variants/libnmpc_experiments.so: tests and scripts only -- the shipped library reads no environment)
+    if (const char *env = getenv("NMPC_SHAPE")) {              // force the run-time-shape kernel
         if (!strcmp(env, "any")) h->shape_default = h->shape_nobs50 = h->shape_n40 = false;
     }
+#endif
     h->map = make_map(*pb, h->P == 40 ? 64 : h->P);      // (P = 40: the kernels compute their own map, nmpc_solve_hyb2.h)
     h->d_queue = nullptr;
     h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
     h->park_min = 500; h->park_depth = 8;
-    if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // tuning knobs; 0 switches migration off
-    if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
     // long instances time-share beyond this fraction of the resident waves: the favoured half of them for the one-stage kernel (two waves per SIMD),
     // 0.8 for the two-stage kernel (one wave per SIMD); measured flat between 0.4 and 0.7 / 0.5 and 1.0 (profiles/r04/sched_sweep*.txt)
     h->sched_mode = 1; h->sched_theta = h->P == 20 ? 0.5 : 0.8;
-    if (const char *env = getenv("NMPC_SCHED")) h->sched_mode = atoi(env);
-    if (const char *env = getenv("NMPC_SCHED_THETA")) { const double v = atof(env); if (v > 0.0) h->sched_theta = v; }
     h->sched_cold = 0.4;
-    if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
     h->team_owners_forced = 0;
     h->team_help = 1;
     // culling radius: what the input bounds let the robot travel in a horizon, plus a margin (any value is exact: an evaluation
     // with a stage beyond it scans every circle); NMPC_CULL_RADIUS overrides it (tests use 0.5 m: the fall-back runs all the time)
     h->cull_radius = 1.1 * pb->N * pb->ts * fmax(fabs(pb->vmin), fabs(pb->vmax));
+    h->use_order = true;
+#ifdef NMPC_EXPERIMENTS      // knobs of the experiments build: tests use them to check that every setting gives the same bits, scripts to measure
+    if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // 0 switches the slot migration off
+    if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
+    if (const char *env = getenv("NMPC_SCHED")) h->sched_mode = atoi(env);
+    if (const char *env = getenv("NMPC_SCHED_THETA")) { const double v = atof(env); if (v > 0.0) h->sched_theta = v; }
+    if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
     if (const char *env = getenv("NMPC_CULL_RADIUS")) { const double v = atof(env); if (v > 0.0) h->cull_radius = v; }
     if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
-    h->use_order = true;
-    if (const char *env = getenv("NMPC_ORDER")) h->use_order = atoi(env) != 0;      // experiments: 0 = instances in index order (scripts/sched_ab.py)
+    if (const char *env = getenv("NMPC_ORDER")) h->use_order = atoi(env) != 0;      // 0 = instances in index order
     if (const char *env = getenv("NMPC_TEAM_OWNERS")) { const int v = atoi(env); if (v >= 1 && v <= nmpc::TEAM_WAVES) h->team_owners_forced = v; }
+#endif
     h->d_order = nullptr;
     h->d_cls = nullptr;
     h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
@@ -1382,10 +1391,12 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
         if (per_cu > 8) per_cu = 8;
     }
-    if (const char *env = getenv("NMPC_WAVES_PER_CU")) {       // tuning knob (experiments only)
+#ifdef NMPC_EXPERIMENTS
+    if (const char *env = getenv("NMPC_WAVES_PER_CU")) {
         const int v = atoi(env);
         if (v >= 1 && v <= per_cu && ((h->P != 20 && h->P != 40) || v % nmpc::TEAM_WAVES == 0)) per_cu = v;
     }
+#endif
     if (per_cu < 1) per_cu = 1;
     h->grid_cap = prop.multiProcessorCount * per_cu;
     *out = h;
@@ -1424,7 +1435,9 @@ static void fill_args(const nmpc_handle *h, KArgs &a, int B)
     a.n_p = nmpc_n_p(&h->pb); a.n_u = nmpc_n_u(&h->pb); a.n1 = nmpc_n1(&h->pb); a.n2 = nmpc_n2(&h->pb);
     a.queue = h->d_queue;
     a.inv_ts = 1.0 / h->pb.ts;
+#ifdef NMPC_EXPERIMENTS
     if (const char *env = getenv("NMPC_DEBUG_PRIO")) a.dbg = atoi(env);
+#endif
 }
 
 int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_u, const double *d_y0,
@@ -1450,10 +1463,13 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
             a.order = h->d_order;
         }
         if ((h->P == 20 && (h->park_min > 0 || h->sched_mode > 0)) || (h->P == 40 && h->sched_mode > 0)) {      // instances may leave their wave at outer-iteration boundaries
-            const size_t cap = (size_t)h->max_batch;      // ring buffers: an instance waits in at most one slot at a time
-            if (!h->d_park) {
+            const size_t cap = (size_t)B;                 // ring buffers of this launch: an instance waits in at most one slot at a time
+            const size_t cap_max = (size_t)h->max_batch;
+            if (!h->d_park || !h->d_pool || !h->d_pool_ctr) {      // (all three or none: a half-made set is freed and made again)
+                (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr);
+                h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
                 HIP_TRY(h, hipMalloc((void **)&h->d_park, (size_t)h->max_batch * nmpc::park_stride(h->pb.N) * 8));
-                HIP_TRY(h, hipMalloc((void **)&h->d_pool, nmpc::NPOOLS * cap * sizeof(int)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_pool, nmpc::NPOOLS * cap_max * sizeof(int)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_pool_ctr, (4 * nmpc::NPOOLS + 2) * sizeof(unsigned int)));
             }
             HIP_TRY(h, hipMemsetAsync(h->d_pool, 0xFF, nmpc::NPOOLS * cap * sizeof(int), s));

@@ -54,6 +54,20 @@ __device__ __forceinline__ int ctl_load(lds_int *p) { return __hip_atomic_load(p
 __device__ __forceinline__ void ctl_store(lds_int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int ctl_add(lds_int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// The instance id in an owner's slice (Lpar[19]) guards what a helper lane has learnt about the owner's tables (cross-track window, obstacle
+// certificate): the owner takes the id away (-1) BEFORE it rewrites the tables and puts the new one back AFTER, the helper reads the id before
+// and after its evaluation.  A sequence lock -- so the accesses are atomic (the compiler may neither merge the helper's two reads nor drop
+// the owner's first store) and fenced at workgroup scope (the id is released after / acquired before the table accesses it guards).
+typedef __attribute__((address_space(3))) long long lds_i64;
+__device__ __forceinline__ void guard_store(lds_double *p, double v)
+{
+    __hip_atomic_store((lds_i64 *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double guard_load(const lds_double *p)
+{
+    return __longlong_as_double(__hip_atomic_load((lds_i64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
 // a query point's scalar (psi): every lane of the point's row holds it; rows 0..2 are points 0..2
 __device__ __forceinline__ double point_scalar(double v, int k)
 {
@@ -303,12 +317,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         DynStage dyn;
         // (the instance id goes away BEFORE the tables change and comes back after: a helper still evaluating a cancelled request of the previous
         // instance then finds another id after its evaluation than before it and throws away what it learnt about its window)
-        if (lane == 0) Lpar[19] = -1.0;
+        if (lane == 0) guard_store(Lpar + 19, -1.0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
         WinState ws = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
         ObsCert oc = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate
-        if (lane == 0) Lpar[19] = (double)inst;                      // (helpers tell by it whether their own windows are still this instance's)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) guard_store(Lpar + 19, (double)inst);         // (helpers tell by it whether their own windows are still this instance's)
         unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
         if constexpr (CULL) {
             near = circle_near_mask(a.p + (size_t)inst * a.n_p, N, shape_nobs<SH>(a), lane, a.cull_radius);
@@ -1019,12 +1035,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         unsigned long long near_w = ~0ull;
         if constexpr (CULL) { const double nb_ = Lw[mp.par + 18]; near_w = ((unsigned long long)(unsigned)__double2hiint(nb_) << 32) | (unsigned)__double2loint(nb_); }
         if constexpr (WIN > 0) {            // another instance's reference: what this lane knew about its window is void
-            const double inst_w = Lw[mp.par + 19];
+            const double inst_w = guard_load(Lw + mp.par + 19);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
         eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, OBSC ? &oc_h : nullptr);
         if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
-            if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (guard_load(Lw + mp.par + 19) != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute

@@ -677,11 +677,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
         if (inst < 0) break;
         long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
-        if (lane == 0) Lpar[19] = -1.0;                      // (nmpc_solve_hyb.h: the id is away while the tables change)
+        if (lane == 0) guard_store(Lpar + 19, -1.0);         // (nmpc_solve_hyb.h: the id is away while the tables change)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
         WinState ws[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // this lane's cross-track windows
         ObsCert2 oc = {d2s(0.0), d2s(0.0), d2s(0.0), 0, 0, 0};      // ... and its obstacle certificate
-        if (lane == 0) Lpar[19] = (double)inst;              // (helpers tell by it whether their windows are still this instance's)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) guard_store(Lpar + 19, (double)inst); // (helpers tell by it whether their windows are still this instance's)
 
         // a fresh instance starts from the caller's u0 / y0, a resumed one from its parked state (acquired by pool_pop): u | y | previous gradient
         // in the layout of the caller's arrays, then 16 scalars (park_stride)
@@ -1317,11 +1319,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         double psi, pen;
         D2 egv = d2s(0.0), egw = d2s(0.0), eav, eaw;
         {                                   // another instance's reference: what this lane knew about its windows is void
-            const double inst_w = Lw[mp.par + 19];
+            const double inst_w = guard_load(Lw + mp.par + 19);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }
         }
         eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ws_h, &oc_h);
-        if (Lw[mp.par + 19] != ws_inst) { ws_inst = -1.0; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }      // (the owner moved on meanwhile)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (guard_load(Lw + mp.par + 19) != ws_inst) { ws_inst = -1.0; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }      // (the owner moved on meanwhile)
         // the trial's forward-backward envelope, in the evaluation layout (the same canonical sums as the state layout's)
         const D2 s1_ = fma2(-gam_w, egv, zv), s2_ = fma2(-gam_w, egw, zw);
         const D2 x1_ = D2{s1_.a - (inea ? clampd(s1_.a, vmin, vmax) : s1_.a), s1_.b - (ineb ? clampd(s1_.b, vmin, vmax) : s1_.b)};

@@ -30,9 +30,10 @@ def problem_from_config(cfg: Config) -> _lib.NmpcProblem:
 class BatchSolver:
     """One handle = one problem shape on one GPU.  Not thread-safe; distinct solvers are."""
 
-    def __init__(self, cfg: Config, max_batch: int = 8192, device: int = 0, **opts):
+    def __init__(self, cfg: Config, max_batch: int = 8192, device: int = 0, experiments: bool = False, **opts):
         self.cfg = cfg
-        self.lib = _lib.load_library()                 # raises if the HIP library cannot be had
+        # raises if the HIP library cannot be had.  (experiments: tests / scripts only -- the variant that reads the NMPC_* environment knobs)
+        self.lib = _lib.load_library(experiments=experiments)
         self.pb = problem_from_config(cfg)
         self.opts = _lib.NmpcOpts()
         self.lib.nmpc_default_opts(C.byref(self.opts))

@@ -13,7 +13,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     cfg = named_config(name)
     P = synthetic_batch(cfg, 11, 512, 0, routes=random_routes(cfg, 11, 32, seed=1000),
                         synthetic_circles=name == "cfg3", random_dyn=name == "cfg4")
-    sol = BatchSolver(cfg, max_batch=512)
+    sol = BatchSolver(cfg, max_batch=512, experiments=True)
     st = sol.solve(P)[2]
     out = {"B512_ms": round(min((sol.solve(P), sol.last_batch_ms)[1] for _ in range(3)), 3)}
     order = np.argsort(-st["reserved"].astype(np.int64))

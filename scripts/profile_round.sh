@@ -18,9 +18,11 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:$SQ1" "wait:$SQ2"; do
     name=${pass%%:*}; ctrs=${pass#*:}
     rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_one.py > "$OUT/pmc_$name.log" 2>&1
 done
+python -c "from mpc_trajectory_generator_amd import _lib; _lib.build_variant(_lib.EXPERIMENTS)"      # the knobs (NMPC_TEAM_HELP, ...) exist in this variant only
+XLIB=$PWD/mpc_trajectory_generator_amd/csrc/variants/libnmpc_experiments.so
 for pass in "lone_sq:$SQ1" "lone_wait:$SQ2"; do      # ONE wave on the chip: helpers off
     name=${pass%%:*}; ctrs=${pass#*:}
-    NMPC_TEAM_HELP=0 rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_$name.log" 2>&1
+    NMPC_LIB_PATH=$XLIB NMPC_TEAM_HELP=0 rocprofv3 --pmc $ctrs -d "$OUT/pmc_$name" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_$name.log" 2>&1
 done
 rocprofv3 --pmc $SQ1 -d "$OUT/pmc_team_sq" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_team_sq.log" 2>&1      # the same instance with its three helpers
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.log"

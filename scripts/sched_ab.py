@@ -11,7 +11,7 @@ from mpc_trajectory_generator_amd.harness import synthetic_batch
 from mpc_trajectory_generator_amd.frontend import random_routes
 name = sys.argv[1]
 cfg = named_config(name); B = 8192
-s = BatchSolver(cfg, max_batch=B)
+s = BatchSolver(cfg, max_batch=B, experiments=True)
 out = {"cfg": name, "env": os.environ.get("AB_LABEL"), "ms": [], "checksum": []}
 for seed in (0, 1, 2):
     P = synthetic_batch(cfg, 11, B, seed, routes=random_routes(cfg, 11, 32, seed=1000 + seed), synthetic_circles=name == "cfg3", random_dyn=name == "cfg4")

@@ -1,6 +1,6 @@
 """Where an iteration of the hybrid kernel goes (cycles per iteration by section of its loop), for single instances solved alone with
 and without helper waves.  Needs a library built with -DNMPC_PROF2 (the section timers of nmpc_solve_hyb.h):
-    make -C mpc_trajectory_generator_amd/csrc -B OUT=variants/libnmpc_prof2.so EXTRA=-DNMPC_PROF2
+    make -C mpc_trajectory_generator_amd/csrc -B OUT=variants/libnmpc_prof2.so EXTRA="-DNMPC_PROF2 -DNMPC_EXPERIMENTS"      (=2: the evaluation's own sections)
     NMPC_LIB_PATH=mpc_trajectory_generator_amd/csrc/variants/libnmpc_prof2.so python scripts/sections.py [cfgN] [ids...]
 Sections: 0 phase handlers in front of the batch, 1 the batch of inner products, 2 exit test / L-BFGS update, 3 recurrences + direction,
 4 envelope / trial points / request, 5 evaluation, 6 consumption of the trials."""

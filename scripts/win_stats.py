@@ -28,6 +28,8 @@ if sys.argv[1] == "child":
         out["fallback_share"] = round(buf[1] / max(buf[0], 1), 4)
         out["obstacle_certificates"], out["obstacle_scans"] = int(buf[2]), int(buf[3])
         out["obstacle_scan_share"] = round(buf[3] / max(buf[2], 1), 4)
+    out["kernel"], out["source_hash"], out["config"] = sol.kernel_name, _lib.source_hash(), name
+    out["window_full_scan_share"] = out.get("fallback_share")
     out["ms"] = round(min(ms), 2)
     out["checksum"] = float(st["num_inner_iterations"].astype(np.float64).sum() + st["cost"].sum())
     print(json.dumps(out))

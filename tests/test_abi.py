@@ -58,6 +58,17 @@ def test_no_device_fails_loudly():
         BatchSolver(named_config("default"), max_batch=4)
 
 
+def test_shipped_library_reads_no_environment():
+    """The shipped .so carries no NMPC_* knob (the interface it replaces has none, src/path_generator.py:218-222): no such string in
+    the binary, and it says so itself.  Knobs exist only in the experiments variant the tests and scripts build."""
+    path = _lib.build_library()
+    blob = open(path, "rb").read()
+    assert blob.count(b"NMPC_") == 0, sorted(set(re.findall(rb"NMPC_[A-Z0-9_]+", blob)))
+    assert b"getenv" not in blob
+    lib = _lib.load_library()
+    assert lib.nmpc_experiments_build() == 0
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "mpc_trajectory_generator_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -154,7 +154,7 @@ def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
     P = synthetic_batch(cfg, 11, 40, 4242, synthetic_circles=(name == "cfg3"))
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    s = BatchSolver(cfg, max_batch=64)
+    s = BatchSolver(cfg, max_batch=64, experiments=bool(env))
     try:
         assert s.kernel_name == kernel
         assert_same_solution(s.solve(P), oracle_for(cfg).solve_batch(P, threads=8))
@@ -229,14 +229,14 @@ def test_migration_between_wave_slots_is_invisible(monkeypatch):
     P = synthetic_batch(cfg, 11, 2600, 99)
     monkeypatch.setenv("NMPC_PARK_MIN", "20")
     monkeypatch.setenv("NMPC_PARK_DEPTH", "64")
-    s = BatchSolver(cfg, max_batch=2600)
+    s = BatchSolver(cfg, max_batch=2600, experiments=True)
     try:
         gpu = s.solve(P)
     finally:
         s.close()
     assert_same_solution(gpu, oracle_for(cfg).solve_batch(P, threads=8))
     monkeypatch.setenv("NMPC_PARK_MIN", "0")                      # migration off: the same bits
-    s = BatchSolver(cfg, max_batch=2600)
+    s = BatchSolver(cfg, max_batch=2600, experiments=True)
     try:
         off = s.solve(P)
     finally:
@@ -244,7 +244,7 @@ def test_migration_between_wave_slots_is_invisible(monkeypatch):
     assert np.array_equal(off[0], gpu[0]) and np.array_equal(off[2]["reserved"], gpu[2]["reserved"])
     monkeypatch.setenv("NMPC_ORDER", "0")                         # ... and in index order instead of the launch order, scheduler off as well
     monkeypatch.setenv("NMPC_SCHED", "0")
-    s = BatchSolver(cfg, max_batch=2600)
+    s = BatchSolver(cfg, max_batch=2600, experiments=True)
     try:
         plain = s.solve(P)
     finally:
@@ -477,7 +477,7 @@ def test_team_modes_same_bits(monkeypatch, name, B, env):
     P = synthetic_batch(cfg, 11, B, 2718, synthetic_circles=(name == "cfg3"), random_dyn=(name in ("cfg4", "n17", "n35")))
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    s = BatchSolver(cfg, max_batch=B)
+    s = BatchSolver(cfg, max_batch=B, experiments=True)
     try:
         gpu = s.solve(P)
         gpu2 = s.solve(P, u0=gpu[0], y0=gpu[1])            # a warm start: short solves, helpers racing with fast owners
@@ -501,7 +501,7 @@ def test_four_owners_on_short_horizons(monkeypatch, shape):
     cfg = load_config(N_hor=N, Nobs=nobs, Ndynobs=ndyn)
     P = synthetic_batch(cfg, 11, 96, 4242, random_dyn=ndyn > 0)
     monkeypatch.setenv("NMPC_TEAM_OWNERS", "4")
-    s = BatchSolver(cfg, max_batch=96)
+    s = BatchSolver(cfg, max_batch=96, experiments=True)
     try:
         gpu = s.solve(P)
         gpu2 = s.solve(P, u0=gpu[0], y0=gpu[1])
@@ -543,7 +543,7 @@ def test_circle_culling_is_exact(monkeypatch, name, B, radius):
         P[b, off_c + 21:off_c + 24] = (P[b, off_r + 3 * (N // 2)] + 0.2, P[b, off_r + 3 * (N // 2) + 1], 0.6)
     if radius:
         monkeypatch.setenv("NMPC_CULL_RADIUS", radius)
-    s = BatchSolver(cfg, max_batch=B)
+    s = BatchSolver(cfg, max_batch=B, experiments=True)
     try:
         gpu = s.solve(P)
     finally:

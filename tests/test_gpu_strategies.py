@@ -61,8 +61,8 @@ def run_probe(lib):
 def test_two_stage_kernel_same_bits_under_every_scheduler(strategy):
     from mpc_trajectory_generator_amd import _lib
     if strategy.startswith("iterative-ilp"):
+        _lib.load_library()            # (builds the library, and with it build_info.json, if this checkout has none yet)
         check, lib = _lib.build_info().get("codegen_check", {}), None
-        _lib.load_library()
     else:
         check, lib = _lib.build_variant(strategy), _lib.variant_path(strategy)
     assert check.get("ok"), f"code-generation check failed for {strategy}: {check}"
