@@ -99,6 +99,8 @@ struct KArgs {
     int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
     int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
     int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
+    int topk;                  // hybrid kernel, full batches: at most this many waves of the launch help siblings' longest instances before the queue is dry (0 = off)
+    int help_min_pass;         // ... an instance asks for such help once it has run this many passes
     double cull_radius;        // eval_psi's CULL path: circles whose edge is farther than this from the start position are left out of the scan
     // eval kernel only
     const double *ev_c;
@@ -1224,6 +1226,7 @@ struct nmpc_handle {
     double sched_theta, sched_cold;
     int team_owners_forced;    // experiments (NMPC_TEAM_OWNERS): waves per workgroup that take instances, 0 = automatic
     int team_help;             // experiments (NMPC_TEAM_HELP=0): helpers never asked
+    int topk, help_min_pass;   // helpers for the longest instances of a full batch (nmpc_solve_hyb.h)
     double cull_radius;        // eval_psi CULL (NMPC_CULL_RADIUS)
     double *d_park;            // parked solver states, allocated on first use
     int *d_pool;
@@ -1236,6 +1239,11 @@ struct nmpc_handle {
     char *h_pin[2];            // pinned bounce buffers of the host entry points (pageable user memory <-> HBM at DMA speed)
     hipEvent_t pin_ev[2];
     bool staging_ready;        // every staging resource above exists
+    // small batches through the host entry point (the reference's own call is B = 1, src/path_generator.py:385): ONE device arena
+    // [p | c0 | y0 | u | y_out | status] per instance block, one pinned mirror, one copy in (p .. u), one copy out (u .. status), two events kept
+    char *d_small, *h_small;
+    hipEvent_t small_ev[2];
+    bool small_ready;
     nmpc_status *d_st;
     std::string err;
 };
@@ -1330,6 +1338,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->sched_cold = 0.4;
     h->team_owners_forced = 0;
     h->team_help = 1;
+    h->topk = 0; h->help_min_pass = 3000;
     // culling radius: what the input bounds let the robot travel in a horizon, plus a margin (any value is exact: an evaluation
     // with a stage beyond it scans every circle); NMPC_CULL_RADIUS overrides it (tests use 0.5 m: the fall-back runs all the time)
     h->cull_radius = 1.1 * pb->N * pb->ts * fmax(fabs(pb->vmin), fabs(pb->vmax));
@@ -1342,6 +1351,8 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
     if (const char *env = getenv("NMPC_CULL_RADIUS")) { const double v = atof(env); if (v > 0.0) h->cull_radius = v; }
     if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
+    if (const char *env = getenv("NMPC_TOPK")) h->topk = atoi(env);
+    if (const char *env = getenv("NMPC_TOPK_PASS")) h->help_min_pass = atoi(env);
     if (const char *env = getenv("NMPC_ORDER")) h->use_order = atoi(env) != 0;      // 0 = instances in index order
     if (const char *env = getenv("NMPC_TEAM_OWNERS")) { const int v = atoi(env); if (v >= 1 && v <= nmpc::TEAM_WAVES) h->team_owners_forced = v; }
 #endif
@@ -1349,6 +1360,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->d_cls = nullptr;
     h->d_p = h->d_u = h->d_y0 = h->d_c0 = h->d_yout = h->d_psi = h->d_grad = h->d_F1 = h->d_F2 = nullptr;
     h->h_pin[0] = h->h_pin[1] = nullptr; h->pin_ev[0] = h->pin_ev[1] = nullptr; h->staging_ready = false;
+    h->d_small = h->h_small = nullptr; h->small_ev[0] = h->small_ev[1] = nullptr; h->small_ready = false;
     h->d_st = nullptr;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_queue, sizeof(unsigned int));
@@ -1410,6 +1422,8 @@ void nmpc_free(nmpc_handle *h)
     (void)hipFree(h->d_queue); (void)hipFree(h->d_order); (void)hipFree(h->d_cls);
     (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr);
     for (int k = 0; k < 2; ++k) { if (h->h_pin[k]) (void)hipHostFree(h->h_pin[k]); if (h->pin_ev[k]) (void)hipEventDestroy(h->pin_ev[k]); }
+    (void)hipFree(h->d_small); if (h->h_small) (void)hipHostFree(h->h_small);
+    for (int k = 0; k < 2; ++k) if (h->small_ev[k]) (void)hipEventDestroy(h->small_ev[k]);
     (void)hipFree(h->d_p); (void)hipFree(h->d_u); (void)hipFree(h->d_y0); (void)hipFree(h->d_c0); (void)hipFree(h->d_yout);
     (void)hipFree(h->d_psi); (void)hipFree(h->d_grad); (void)hipFree(h->d_F1); (void)hipFree(h->d_F2); (void)hipFree(h->d_st);
     delete h;
@@ -1498,6 +1512,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         a.sched_long_cap = (int)(h->sched_theta * (double)(wgs * owners));
         a.sched_cold_cap = (int)(h->sched_cold * (double)(wgs * owners));
         a.team_help = h->team_help;
+        a.topk = (h->P == 20 && a.pool_ctr) ? h->topk : 0; a.help_min_pass = h->help_min_pass;
         a.cull_radius = h->cull_radius;
 #ifdef NMPC_PROFILE
         const size_t tlds = lds;
@@ -1616,6 +1631,45 @@ static hipError_t d2h_staged(nmpc_handle *h, void *dst, const void *src, size_t 
     return e;
 }
 
+static constexpr int SMALL_BATCH = 16;      // instances the small-batch arena holds
+static int solve_small_host(nmpc_handle *h, int B, const double *p, double *u, const double *y0, const double *c0,
+                            double *y_out, nmpc_status *status)
+{
+    const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb);
+    const size_t cap = SMALL_BATCH;
+    const size_t o_p = 0, o_c = o_p + cap * np * 8, o_y = o_c + cap * 8, o_u = o_y + cap * n1 * 8, o_yo = o_u + cap * nu * 8,
+                 o_st = o_yo + cap * n1 * 8, total = o_st + cap * sizeof(nmpc_status);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->small_ready) {
+        if (h->d_small) return fail(h, NMPC_ERR_HIP, "small-batch arena: an earlier allocation failed half way");
+        HIP_TRY(h, hipMalloc((void **)&h->d_small, total));
+        HIP_TRY(h, hipHostMalloc((void **)&h->h_small, total, hipHostMallocDefault));
+        for (int k = 0; k < 2; ++k) HIP_TRY(h, hipEventCreate(&h->small_ev[k]));
+        h->small_ready = true;
+    }
+    char *hs = h->h_small, *ds = h->d_small;
+    // in: p .. u of the B instances (each array at its arena offset; only what is used travels, as one copy from the first to the last byte used)
+    std::memcpy(hs + o_p, p, B * np * 8);
+    if (c0) std::memcpy(hs + o_c, c0, B * 8);
+    if (y0) std::memcpy(hs + o_y, y0, B * n1 * 8);
+    std::memcpy(hs + o_u, u, B * nu * 8);
+    HIP_TRY(h, hipMemcpyAsync(ds, hs, o_u + B * nu * 8, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(h, hipEventRecord(h->small_ev[0], nullptr));
+    const int rc = nmpc_solve_batch_device(h, B, (const double *)(ds + o_p), (double *)(ds + o_u), y0 ? (const double *)(ds + o_y) : nullptr,
+                                           c0 ? (const double *)(ds + o_c) : nullptr, (double *)(ds + o_yo), (nmpc_status *)(ds + o_st), nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->small_ev[1], nullptr));
+    HIP_TRY(h, hipMemcpyAsync(hs + o_u, ds + o_u, total - o_u, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->small_ev[0], h->small_ev[1]));
+    h->last_ms = (double)ms;
+    std::memcpy(u, hs + o_u, B * nu * 8);
+    if (y_out) std::memcpy(y_out, hs + o_yo, B * n1 * 8);
+    if (status) std::memcpy(status, hs + o_st, B * sizeof(nmpc_status));
+    return NMPC_OK;
+}
+
 int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, const double *y0, const double *c0,
                           double *y_out, nmpc_status *status)
 {
@@ -1623,6 +1677,7 @@ int nmpc_solve_batch_host(nmpc_handle *h, int B, const double *p, double *u, con
     if (!h->alive) return NMPC_ERR_DEAD_HANDLE;
     if (B < 0 || B > h->max_batch || (B > 0 && (!p || !u))) return fail(h, NMPC_ERR_BAD_ARG, "bad batch arguments");
     if (B == 0) return NMPC_OK;
+    if (B <= SMALL_BATCH) return solve_small_host(h, B, p, u, y0, c0, y_out, status);
     int rc = ensure_staging(h);
     if (rc) return rc;
     const size_t np = nmpc_n_p(&h->pb), nu = nmpc_n_u(&h->pb), n1 = nmpc_n1(&h->pb);

@@ -84,7 +84,7 @@ struct LdsMap2 {
     int vec;      // 7 parked state-layout vectors: 24 entries of 4 doubles each (state lanes 24..31 share entry 23: zeros)
     int gsy, gyy; // Gram-form L-BFGS (nmpc_solve_hyb.h): the kept inner products [slot][slot]
     int S, Y;     // L-BFGS ring: MAXMEM slots x 21 entries (20 lane pairs + a zero column) of 4 doubles
-    int nv;       // ... the four vectors of an iteration -- s | y | r | g -- in the ring's shape
+    int nv;       // ... the four vectors of an iteration -- s | y | r | g -- in the ring's shape (shares the place of pts | grd)
     int total;
 };
 #ifndef NMPC_WIN2
@@ -120,7 +120,9 @@ __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
     mp.gyy = o; o += MAXMEM * MAXMEM;
     mp.S = o;   o += MAXMEM * H2_NS * 4;
     mp.Y = o;   o += MAXMEM * H2_NS * 4;
-    mp.nv = o;  o += 4 * H2_NS * 4;
+    // (the four vectors live from the top of a pass to the end of its L-BFGS phase; the query points and gradients of the pass, which are
+    // written after that and dead before the next one, share their place: 336 of 576 doubles)
+    mp.nv = mp.pts;
     mp.total = (o + 1) & ~1;
     return mp;
 }
