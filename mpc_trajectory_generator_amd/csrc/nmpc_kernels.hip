@@ -99,8 +99,6 @@ struct KArgs {
     int dbg;                   // experiments (NMPC_DEBUG_PRIO): static wave priorities + per-instance cycle counts
     int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
     int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
-    int topk;                  // hybrid kernel, full batches: at most this many waves of the launch help siblings' longest instances before the queue is dry (0 = off)
-    int help_min_pass;         // ... an instance asks for such help once it has run this many passes
     double cull_radius;        // eval_psi's CULL path: circles whose edge is farther than this from the start position are left out of the scan
     // eval kernel only
     const double *ev_c;
@@ -1226,7 +1224,6 @@ struct nmpc_handle {
     double sched_theta, sched_cold;
     int team_owners_forced;    // experiments (NMPC_TEAM_OWNERS): waves per workgroup that take instances, 0 = automatic
     int team_help;             // experiments (NMPC_TEAM_HELP=0): helpers never asked
-    int topk, help_min_pass;   // helpers for the longest instances of a full batch (nmpc_solve_hyb.h)
     double cull_radius;        // eval_psi CULL (NMPC_CULL_RADIUS)
     double *d_park;            // parked solver states, allocated on first use
     int *d_pool;
@@ -1338,7 +1335,6 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     h->sched_cold = 0.4;
     h->team_owners_forced = 0;
     h->team_help = 1;
-    h->topk = 0; h->help_min_pass = 3000;
     // culling radius: what the input bounds let the robot travel in a horizon, plus a margin (any value is exact: an evaluation
     // with a stage beyond it scans every circle); NMPC_CULL_RADIUS overrides it (tests use 0.5 m: the fall-back runs all the time)
     h->cull_radius = 1.1 * pb->N * pb->ts * fmax(fabs(pb->vmin), fabs(pb->vmax));
@@ -1351,8 +1347,6 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
     if (const char *env = getenv("NMPC_CULL_RADIUS")) { const double v = atof(env); if (v > 0.0) h->cull_radius = v; }
     if (const char *env = getenv("NMPC_TEAM_HELP")) h->team_help = atoi(env) != 0;
-    if (const char *env = getenv("NMPC_TOPK")) h->topk = atoi(env);
-    if (const char *env = getenv("NMPC_TOPK_PASS")) h->help_min_pass = atoi(env);
     if (const char *env = getenv("NMPC_ORDER")) h->use_order = atoi(env) != 0;      // 0 = instances in index order
     if (const char *env = getenv("NMPC_TEAM_OWNERS")) { const int v = atoi(env); if (v >= 1 && v <= nmpc::TEAM_WAVES) h->team_owners_forced = v; }
 #endif
@@ -1512,7 +1506,6 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         a.sched_long_cap = (int)(h->sched_theta * (double)(wgs * owners));
         a.sched_cold_cap = (int)(h->sched_cold * (double)(wgs * owners));
         a.team_help = h->team_help;
-        a.topk = (h->P == 20 && a.pool_ctr) ? h->topk : 0; a.help_min_pass = h->help_min_pass;
         a.cull_radius = h->cull_radius;
 #ifdef NMPC_PROFILE
         const size_t tlds = lds;

@@ -49,7 +49,7 @@ namespace nmpc {
 
 typedef __attribute__((address_space(3))) int lds_int;
 // control block of a workgroup, after the four slices
-enum { CTL_OWNERS = 0, CTL_HELPERS = 1, CTL_TEMP = 2, CTL_CLAIM = 4, CTL_DONE = 8, CTL_WANT = 56 };     // done: [owner][task][helper]; want: [owner]
+enum { CTL_OWNERS = 0, CTL_HELPERS = 1, CTL_CLAIM = 4, CTL_DONE = 8 };     // done: [owner][task][helper]
 __device__ __forceinline__ int ctl_load(lds_int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ctl_store(lds_int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int ctl_add(lds_int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -289,43 +289,29 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // A wave is first the OWNER of the instances it takes from the queue (the loop right below); once there is nothing left
     // for it -- or from the start, for the waves beyond team_owners in the small-batch mode -- it is a HELPER of its siblings
     // (the loop at the end) until the last of them has finished.
-    // Helpers for the longest instances (KArgs.topk > 0; full batches): an owner whose instance has run help_min_pass passes raises a flag in
-    // the workgroup's control block; a sibling that comes back for work while the flag is up -- and fewer than topk waves of the whole launch
-    // are doing so -- helps it until the instance ends (a TEMPORARY helper: it then takes instances again) instead of fetching.  A batch ends
-    // with its longest instance, and a helped iteration is a quarter faster; what it costs is the helpers' own throughput.
-    bool permanent = !(wid < a.team_owners);         // no instances for this wave (any more): a helper until its workgroup is done
-    for (;;) {                                       // ---- the wave's life: owner phases and helper phases
-    if (!permanent) for (;;) {
+    // (Measured and not taken, round 5: helpers for the K longest instances of a full batch BEFORE the queue is dry -- a sibling that comes
+    // back for work helps a flagged long instance instead of fetching.  Same bits; cfg 1 -0.1 .. +0.6 %, cfg 3 -1.4 % for K = 16 .. 256:
+    // with the step-aside scheduling the long instances time-share the waves, so the end of a batch is their throughput, not one
+    // instance's latency.  profiles/r05/topk_helpers.jsonl, topk_helpers.patch.)
+    for (; wid < a.team_owners;) {
         // ------------------------------------------------------------------ next instance: parked long-runners first
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
         if (lane == 0) {
             const bool pools = a.park_min > 0 || a.sched_mode > 0;
-            if (a.topk > 0 && pools) {
-                int wants = 0;
-                for (int w = 0; w < TEAM_WAVES; ++w) wants += (w != wid && ctl_load(ctl + CTL_WANT + w) != 0) ? 1 : 0;
-                if (wants > ctl_load(ctl + CTL_TEMP)) {
-                    unsigned int *gk = a.pool_ctr + POOL_CTRS * NPOOLS + 1;
-                    if (__hip_atomic_fetch_add(gk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.topk) fetched = -2;
-                    else __hip_atomic_fetch_add(gk, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (fetched != -2) {
-                if (pools && !unfavoured) { fetched = pool_pop(a, POOL_LONG); from_pool = fetched >= 0; }      // favoured waves: waiting long-runners first
-                if (fetched < 0) {
-                    const unsigned nxt = atomicAdd(a.queue, 1u);
-                    if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
-                    else if (pools) {
-                        for (int c = 0; c < NPOOLS && fetched < 0; ++c) fetched = pool_pop(a, c);
-                        from_pool = fetched >= 0;
-                    }
+            if (pools && !unfavoured) { fetched = pool_pop(a, POOL_LONG); from_pool = fetched >= 0; }      // favoured waves: waiting long-runners first
+            if (fetched < 0) {
+                const unsigned nxt = atomicAdd(a.queue, 1u);
+                if (nxt < (unsigned)a.B) fetched = a.order ? a.order[nxt] : (int)nxt;
+                else if (pools) {
+                    for (int c = 0; c < NPOOLS && fetched < 0; ++c) fetched = pool_pop(a, c);
+                    from_pool = fetched >= 0;
                 }
             }
         }
         const int inst = __builtin_amdgcn_readfirstlane(fetched);
         const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
-        if (inst == -2) break;                        // a sibling's long instance wants help: a temporary helper
-        if (inst < 0) { permanent = true; break; }   // nothing left for this wave: a helper from now on
+        if (inst < 0) break;     // nothing left for this wave: a helper from now on
 
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
         // (experiments, scripts/slot_probe.py: first start and migration count travel with the instance; parked in LDS)
@@ -397,7 +383,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         int park_cls = POOL_LONG;
         unsigned q_pass = 0;                      // n_pass at the last outer-iteration boundary (or at the start of this leg)
         bool long_counted = false;                 // this instance is in the count of long instances alive (KArgs.pool_ctr[2 NPOOLS])
-        bool want_me = false;                      // this instance has asked its siblings for helpers (KArgs.topk)
         if (resumed) {                            // parked scalars
             const double *pks = a.park + (size_t)inst * PS + 6 * N;
             pen_c = pks[0];
@@ -478,10 +463,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 }
             }
             // ---------------------------------------------------------------- start of a PANOC step
-            if (f_begin) {
-                rv = uv - hv; rw = uw - hw; lb_batch = true;
-                if (a.topk > 0 && !want_me && n_pass >= (unsigned)a.help_min_pass) { want_me = true; if (lane == 0) ctl_store(ctl + CTL_WANT + wid, 1); }
-            }
+            if (f_begin) { rv = uv - hv; rw = uw - hw; lb_batch = true; }
             NMPC_SEC(pf0);
             // ---- the batch of inner products of this step (Gram-form L-BFGS, see the top of the file)
             double gU = 0.0, gs1 = 0.0, gs2 = 0.0, gy1 = 0.0, gy2 = 0.0;
@@ -626,8 +608,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     yqw = fma(-0.5, dw, fma(-0.5, rw, uw));
                     need_grad = true; state = D_ITER;
                     // team: idle waves of this workgroup evaluate the trials tau = 2^-2 .. 2^-10 of this direction meanwhile
-                    if (a.team_help && (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0 ||
-                                        (want_me && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_TEMP)) > 0))) {
+                    if (a.team_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
                         if (in && h == 0) { Lreq[t] = dbl2{uv, uw}; Lreq[24 + t] = dbl2{rv, rw}; Lreq[48 + t] = dbl2{dv, dw}; }
                         if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; Lpar[17] = gamma; }
                         team_seq = team_seq >= 0xffff0u ? 1u : team_seq + 1u;
@@ -943,7 +924,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             NMPC_SEC(pf6);
         }
 
-        if (want_me && lane == 0) ctl_store(ctl + CTL_WANT + wid, 0);
         // ------------------------------------------------------------------ parked: state out, into the pool
         if (parked) {
             double *po = a.park + (size_t)inst * PS;
@@ -1017,20 +997,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // This wave's slice is free now; it holds the result areas, one per (owner, task).
     if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
     if (lane == 0) {
-        if (permanent && wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
-        ctl_add(ctl + (permanent ? CTL_HELPERS : CTL_TEMP), 1);
+        if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
+        ctl_add(ctl + CTL_HELPERS, 1);
     }
     WinState ws_h = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this helper lane's cross-track window, valid for the instance `ws_inst`
     ObsCert oc_h = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate, likewise
     double ws_inst = -1.0;
     for (;;) {
-        if (!a.team_help) break;                                                                          // (nobody will ask: NMPC_TEAM_HELP=0)
-        if (permanent) { if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break; }
-        else {          // a temporary helper stays while a sibling's long instance is running
-            int wants = 0;
-            if (lane == 0) for (int w = 0; w < TEAM_WAVES; ++w) wants += (w != wid && ctl_load(ctl + CTL_WANT + w) != 0) ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(wants) == 0) break;
-        }
+        if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         // claim the next open task of some sibling's request
         int got = -1;
         if (lane == 0) {
@@ -1089,12 +1063,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) ctl_store(ctl + CTL_DONE + (w * 3 + k) * TEAM_WAVES + wid, seq);
     }
-    if (permanent) break;
-    if (lane == 0) {      // the long instance has ended: back to taking instances
-        ctl_add(ctl + CTL_TEMP, -1);
-        __hip_atomic_fetch_add(a.pool_ctr + POOL_CTRS * NPOOLS + 1, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    }                     // ---- (the wave's life)
 }
 #undef pk_eps_nu
 #undef pk_dy_norm
