@@ -328,16 +328,28 @@ __device__ long long nmpc_dummy_;
 // CULL: `near` is the set of static circles that can be touched at all while every stage stays within KArgs.cull_radius of the start
 // position (circle_near_mask below); the activity scan visits those only, and falls back to all of them for an evaluation in
 // which some stage is farther away -- so the result is exactly that of the full scan.
+// The handful of launch-uniform scalars an evaluation reads, as values of their own.  Read from the argument block (a.pb.*) they belong to a
+// sixteen-dword scalar load whose registers the allocator spills and reloads AS ONE (sixteen v_readlane per use of one bound); a kernel that
+// hands them over in this struct -- each passed through scalar_own() once -- pays two.
+struct EvK { double ts, inv_ts, amin, amax, awmax; };
+__device__ __forceinline__ double scalar_own(double x)
+{
+    // through a vector register and back (v_readfirstlane): a definition of its own that the coalescer cannot fold back into the loaded tuple
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(hi), __builtin_amdgcn_readfirstlane(lo));
+}
 template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, int WIN = 0>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
                                          double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, WinState *ws = nullptr,
-                                         ObsCert *oc = nullptr, long long *nmpc_pe = nullptr)
+                                         ObsCert *oc = nullptr, long long *nmpc_pe = nullptr, const EvK *ek = nullptr)
 {
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
-    const double ts = a.pb.ts, inv_ts = a.inv_ts;
+    const double ts = ek ? ek->ts : a.pb.ts, inv_ts = ek ? ek->inv_ts : a.inv_ts;
+    const double k_amin = ek ? ek->amin : a.pb.amin, k_amax = ek ? ek->amax : a.pb.amax, k_awmax = ek ? ek->awmax : a.pb.awmax;
     (void)nmpc_pe;
     // every stage lane of the tri layout is inside a 20-stage horizon; lanes 60..63 then hold
     // don't-care values that no cross-lane operation lets into the other lanes (nmpc_device.h)
@@ -489,8 +501,8 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     acc = fma(sc[SC_PA] * av, av, acc);
     acc = fma(sc[SC_PW] * aw, aw, acc);
     const double tv = fma(yv, cbar_inv, av), tw = fma(yw, cbar_inv, aw);
-    double sv = tv - clampd(tv, a.pb.amin, a.pb.amax);
-    double sw = tw - clampd(tw, -a.pb.awmax, a.pb.awmax);
+    double sv = tv - clampd(tv, k_amin, k_amax);
+    double sw = tw - clampd(tw, -k_awmax, k_awmax);
     acc = fma(half_c, fma(sv, sv, sw * sw), acc);
     if (t == N - 1) {                                                             // terminal (:148)
         const double tx = xn - xf, ty = yn - yf, tth = thn - thf;

@@ -248,7 +248,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     __syncthreads();
     lds_double2 *Lreq = (lds_double2 *)(L + mp.req);      // this wave's request: u | r | d by stage
     unsigned team_seq = 0;                                // sequence number of this wave's requests
-    const double vmin = a.pb.vmin, vmax = a.pb.vmax, wmax = a.pb.wmax;
+    const double vmin = scalar_own(a.pb.vmin), vmax = scalar_own(a.pb.vmax), wmax = scalar_own(a.pb.wmax);
+    const EvK ek = {scalar_own(a.pb.ts), scalar_own(a.inv_ts), scalar_own(a.pb.amin), scalar_own(a.pb.amax), scalar_own(a.pb.awmax)};
+    const double tol_ = scalar_own(a.op.tolerance);
     const unsigned max_inner = (unsigned)a.op.max_inner;
     const unsigned budget = (unsigned)a.op.max_total_inner;     // 0 = off
     lds_double *Lpar = L + mp.par;
@@ -407,6 +409,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #define NMPC_SEC_RAW(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define NMPC_SEC(acc) do { long long t_; NMPC_SEC_RAW(t_); acc += t_ - pf_last; pf_last = t_; } while (0)
         NMPC_SEC_RAW(pf_last);
+#elif defined(NMPC_MARKS)      // section markers in the ISA dump (scripts/isa_stats.py)
+#define NMPC_SEC(acc) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK S_" #acc); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define NMPC_SEC(acc) do { } while (0)
 #endif
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             if (f_begin) {
                 f_begin = false;
                 bool exit_now = false;
-                if (__any(norm_r < a.op.tolerance)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
+                if (__any(norm_r < tol_)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
                     if (a.op.akkt_gradient == 2) exit_now = true;
                     else {
                         const dbl2 q_ = *Lq;
@@ -672,9 +676,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
 #if defined(NMPC_PROF2) && NMPC_PROF2 == 2
             NMPC_SEC_RAW(pe[7]);
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, pe);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, pe, &ek);
 #else
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr);
+            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, nullptr, &ek);
 #endif
 #ifdef NMPC_PROF2
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
@@ -848,8 +852,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
-                const double ypv = inea ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
-                const double ypw = inea ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
+                const double ypv = inea ? fma(pen_c, eav - clampd(tv, ek.amin, ek.amax), yv) : 0.0;
+                const double ypw = inea ? fma(pen_c, eaw - clampd(tw, -ek.awmax, ek.awmax), yw) : 0.0;
                 *LypE = dbl2{ypv, ypw};
                 const double d1 = ypv - yv, d2 = ypw - yw;
                 pk_dy_norm_plus = sqrt(group_sum<PE>(inea ? fma(d1, d1, d2 * d2) : 0.0, lane));
@@ -1043,7 +1047,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
-        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, OBSC ? &oc_h : nullptr);
+        eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, OBSC ? &oc_h : nullptr, nullptr, &ek);
         if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (guard_load(Lw + mp.par + 19) != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
