@@ -642,22 +642,36 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
         for (unsigned long long rem = act; rem;) {          // two touched circles per trip: their tree sums interleave
             const int k0 = __builtin_ctzll(rem);
             rem &= rem - 1;
-            const bool two = rem != 0ull;
-            const int k1 = two ? __builtin_ctzll(rem) : k0;
-            rem &= rem - (two ? 1ull : 0ull);
+            if (rem == 0ull) {
+                // a single circle left (the usual case of an instance that grazes an obstacle): one sum, not a pair with a dummy twin
+                const lds_double *o0 = L + mp.obs + OBS_STRIDE * k0;
+                const double ax = o0[0], ay = o0[1], ar = o0[2];
+                const double dx0 = xn - ax, dy0 = yn - ay;
+                const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar));
+                const double f20 = group_sum<P>(in ? fmax(h0, 0.0) : 0.0, lane);
+                if (WRITE_F2 && t == 0) L[f2off + k0] = f20;
+                pen = fma(f20, f20, pen);
+                if (want_grad) {
+                    const double w0 = -2.0 * (c * f20);
+                    if (h0 > 0.0) { gx = fma(w0, dx0, gx); gy = fma(w0, dy0, gy); }
+                }
+                break;
+            }
+            const int k1 = __builtin_ctzll(rem);
+            rem &= rem - 1;
             const lds_double *o0 = L + mp.obs + OBS_STRIDE * k0, *o1 = L + mp.obs + OBS_STRIDE * k1;
             const double ax = o0[0], ay = o0[1], ar = o0[2], bx = o1[0], by = o1[1], br = o1[2];
             const double dx0 = xn - ax, dy0 = yn - ay, dx1 = xn - bx, dy1 = yn - by;
             const double h0 = fma(-dy0, dy0, fma(-dx0, dx0, ar)), h1 = fma(-dy1, dy1, fma(-dx1, dx1, br));
             const double f20 = group_sum<P>(in ? fmax(h0, 0.0) : 0.0, lane);
             const double f21 = group_sum<P>(in ? fmax(h1, 0.0) : 0.0, lane);
-            if (WRITE_F2 && t == 0) { L[f2off + k0] = f20; if (two) L[f2off + k1] = f21; }
+            if (WRITE_F2 && t == 0) { L[f2off + k0] = f20; L[f2off + k1] = f21; }
             pen = fma(f20, f20, pen);
-            if (two) pen = fma(f21, f21, pen);
+            pen = fma(f21, f21, pen);
             if (want_grad) {
                 const double w0 = -2.0 * (c * f20), w1 = -2.0 * (c * f21);
                 if (h0 > 0.0) { gx = fma(w0, dx0, gx); gy = fma(w0, dy0, gy); }
-                if (two && h1 > 0.0) { gx = fma(w1, dx1, gx); gy = fma(w1, dy1, gy); }
+                if (h1 > 0.0) { gx = fma(w1, dx1, gx); gy = fma(w1, dy1, gy); }
             }
         }
 #pragma unroll
