@@ -60,4 +60,23 @@ for k in fetch:
 with open(os.path.join(out, "traffic.json"), "w") as fh:
     json.dump(entries, fh, indent=1)
 print(json.dumps(entries))
-print(open(os.path.join(out, "bench.json")).read().strip()[:400])
+# scan_shares.json: share of the evaluations in which the exact certificates of eval_psi fell back (scripts/win_stats.py on a -DNMPC_WIN_STATS
+# build), keyed like the traffic -- bench.py derives roofline.executed_frac from it
+ws = os.path.join(out, "win_stats.txt")
+if os.path.exists(ws):
+    shares = []
+    for line in open(ws):
+        i = line.find("{")
+        if i >= 0:
+            try:
+                d = json.loads(line[i:])
+            except ValueError:
+                continue
+            shares.append({k: d.get(k) for k in ("kernel", "source_hash", "config", "searches", "fallbacks", "window_full_scan_share",
+                                                 "obstacle_certificates", "obstacle_scans", "obstacle_scan_share")})
+    with open(os.path.join(out, "scan_shares.json"), "w") as fh:
+        json.dump(shares, fh, indent=1)
+    print(json.dumps(shares))
+b = os.path.join(out, "bench.json")
+if os.path.exists(b):
+    print(open(b).read().strip()[:400])
