@@ -406,7 +406,7 @@ def main():
         del u_cold, y_cold
         step(warm=False)                                                   # leave the cold-start results in the buffers
         fence()
-    # (b2) the other values of the one restatement switch that moves the headline by a large factor (DESIGN.md section 9.1),
+    # (b2) the other values of the one restatement switch that moves the headline by a large factor (DESIGN.md section 9),
     # timed by HIP events on the same batch, one warm-up + one timed step each
     variants = None
     if extras_ok:

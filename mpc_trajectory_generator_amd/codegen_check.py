@@ -1,5 +1,5 @@
 """Build-time validation of the generated gfx950 code: two classes of wrong code that ROCm 7.2's LLVM produces for these kernels and that
-neither the compiler nor its machine verifier reports (DESIGN.md section 5.9).  `verify()` compiles csrc/nmpc_kernels.hip once more with the
+neither the compiler nor its machine verifier reports (DESIGN.md section 5.8).  `verify()` compiles csrc/nmpc_kernels.hip once more with the
 flags of the real build plus machine-code dumps and checks
 
 1. the machine scheduler: every virtual-register lane an instruction reads must come from the same defining instruction after scheduling

@@ -35,7 +35,7 @@ def test_sizes_and_struct_layout():
     o = _lib.NmpcOpts()
     lib.nmpc_default_opts(ctypes.byref(o))
     assert (o.tolerance, o.lbfgs_memory, o.max_inner, o.max_outer, o.initial_penalty) == (1e-4, 10, 500, 10, 1.0)
-    # the budget is off; akkt_gradient defaults to 1 (step_top, DESIGN.md section 9.1), the other switches to 0
+    # the budget is off; akkt_gradient defaults to 1 (step_top, DESIGN.md section 9), the other switches to 0
     assert (o.max_total_inner, o.akkt_gradient, o.ls_failure, o.inner_status) == (0, 1, 0, 0)
 
 

@@ -1,4 +1,4 @@
-"""The build gate of DESIGN.md section 5.9 (mpc_trajectory_generator_amd/codegen_check.py) against the machine code that made it necessary:
+"""The build gate of DESIGN.md section 5.8 (mpc_trajectory_generator_amd/codegen_check.py) against the machine code that made it necessary:
 two excerpts of LLVM MIR dumps of this project's own earlier sources (tests/golden/mir_*.txt, a dozen instructions each) -- the minimal
 cases of the two compiler defects -- and their repaired counterparts.  CPU only, no compilation."""
 import os

@@ -89,7 +89,7 @@ def test_pass_model_of_the_oracle_equals_the_kernels_pass_counter(solvers):
     """The oracle also counts how many evaluation passes a three-points-per-pass schedule needs for its (sequential)
     run -- u and u + h together; u_bar with the first two trials; further trials three at a time; a pass per Lipschitz
     back-off -- and the hybrid kernel counts the passes it actually executed.  Equal on every instance: the kernel
-    wastes no pass, and the 6-point figure the same model gives (DESIGN.md section 5.6, helper waves) can be trusted."""
+    wastes no pass, and the 6-point figure the same model gives (DESIGN.md section 5.5, helper waves) can be trusted."""
     cfg = named_config("cfg1")
     P = synthetic_batch(cfg, 11, 96, 4711)
     _, _, st = solvers("cfg1").solve(P)
