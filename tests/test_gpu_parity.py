@@ -553,6 +553,64 @@ def test_circle_culling_is_exact(monkeypatch, name, B, radius):
     assert (cpu[2]["penalty"] > 1.0).any() and (cpu[2]["num_outer_iterations"] > 2).any()      # the circles did matter
 
 
+@pytest.mark.parametrize("case", ["on-path", "edge", "rings", "ellipses", "warm-jump"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg3", "cfg4", "cfg2"])
+def test_obstacle_certificate_is_exact(monkeypatch, name, case):
+    """The shape-specialised three-point kernels skip the circle / ellipse activity scan of an evaluation while every stage has moved
+    less than its clearance from the obstacles the last scan found untouched (eval_psi / eval_psi2, ObsCert) -- exact only if no
+    obstacle can be entered unnoticed.  Obstacle fields built to defeat it -- circles dropped ONTO the reference (stages start
+    inside), circles whose edge passes through reference samples (clearance ~ 0, sign of h at the rounding level), concentric
+    rings of tiny and huge circles around the robot, fat ellipses crossing the horizon, warm starts from a far-away control
+    sequence (every stage jumps by metres between the first evaluations) -- give the oracle's bits, and for N_hor <= 20 those of
+    the run-time-shape kernel, which has no certificate."""
+    from mpc_trajectory_generator_amd.solver import BatchSolver
+    cfg = named_config(name)
+    B, N = 48, cfg.N_hor
+    P = synthetic_batch(cfg, 11, B, 4711, synthetic_circles=(name == "cfg3"), random_dyn=(name in ("cfg4", "cfg2") or case == "ellipses"))
+    off_c, off_d, off_r = 20 + N, 20 + N + 3 * cfg.Nobs, cfg.n_p - 3 * N
+    rng = np.random.default_rng(11)
+    u0 = None
+    for b in range(B):
+        ref = P[b, off_r:].reshape(N, 3)
+        if case == "on-path":
+            for k in range(min(4, cfg.Nobs)):
+                t = int(rng.integers(1, N))
+                P[b, off_c + 3 * k:off_c + 3 * k + 3] = (ref[t, 0] + rng.normal(0, 0.1), ref[t, 1] + rng.normal(0, 0.1), rng.uniform(0.2, 0.8))
+        elif case == "edge":
+            for k in range(min(6, cfg.Nobs)):
+                t = int(rng.integers(0, N)); r = rng.uniform(0.3, 1.5); a = rng.uniform(0, 2 * np.pi)
+                P[b, off_c + 3 * k:off_c + 3 * k + 3] = (ref[t, 0] + r * np.cos(a), ref[t, 1] + r * np.sin(a), r)
+        elif case == "rings":
+            for k in range(cfg.Nobs):
+                r = 10.0 ** rng.uniform(-3, 1.2)
+                P[b, off_c + 3 * k:off_c + 3 * k + 3] = (P[b, 0] + rng.normal(0, 0.5), P[b, 1] + rng.normal(0, 0.5), r)
+        elif case == "ellipses":
+            for k in range(cfg.Ndynobs):
+                for t in range(N):
+                    o = off_d + (k * N + t) * 5
+                    P[b, o:o + 5] = (ref[t, 0] + 0.3 * np.sin(0.4 * t + k), ref[t, 1] + 0.3 * np.cos(0.3 * t), rng.uniform(0.2, 2.5), rng.uniform(0.05, 0.6), rng.uniform(0, np.pi))
+    if case == "warm-jump":
+        u0 = np.tile(np.array([cfg.lin_vel_max, cfg.ang_vel_max]), (B, N)) * rng.choice([-0.3, 1.0], size=(B, 1))
+    s = BatchSolver(cfg, max_batch=B)
+    try:
+        assert "Shape" in s.kernel_name and "ShapeAny" not in s.kernel_name
+        gpu = s.solve(P, u0=u0)
+    finally:
+        s.close()
+    cpu = oracle_for(cfg).solve_batch(P, u0=u0, threads=8)
+    assert_same_solution(gpu, cpu)
+    if case in ("on-path", "edge", "rings"):
+        assert (cpu[2]["penalty"] > 1.0).any()                      # the obstacles did matter
+    if N <= 20:
+        monkeypatch.setenv("NMPC_SHAPE", "any")
+        s = BatchSolver(cfg, max_batch=B, experiments=True)
+        try:
+            assert s.kernel_name.endswith("<ShapeAny>")
+            assert_same_solution(s.solve(P, u0=u0), gpu)
+        finally:
+            s.close()
+
+
 @pytest.mark.parametrize("shape", ["folded", "stationary", "far", "zigzag", "short"])
 @pytest.mark.parametrize("name", ["cfg1", "cfg2", "n6"])
 def test_windowed_cross_track_search_is_exact(name, shape):
