@@ -339,6 +339,11 @@ __device__ __forceinline__ double scalar_own(double x)
     asm volatile("" : "+v"(lo), "+v"(hi));
     return __hiloint2double(__builtin_amdgcn_readfirstlane(hi), __builtin_amdgcn_readfirstlane(lo));
 }
+__device__ __forceinline__ int scalar_own(int x)
+{
+    asm volatile("" : "+v"(x));
+    return __builtin_amdgcn_readfirstlane(x);
+}
 template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, int WIN = 0>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,

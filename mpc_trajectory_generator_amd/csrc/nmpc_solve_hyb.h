@@ -205,7 +205,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     lds_int *ctl = (lds_int *)((lds_double *)lds + TEAM_WAVES * slice);
     const int lane = threadIdx.x & 63, h = lane >> 5, t = lane & 31;
     const int q = lay_group<PE>(lane), te = lay_stage<PE>(lane);
-    const int N = shape_N<SH>(a), m = a.op.lbfgs_memory;
+    // (launch-uniform integers the loop reads -- each a scalar of its own, not a member of the argument block's eight-dword load: scalar_own)
+    const int N = shape_N<SH>(a), m = scalar_own(a.op.lbfgs_memory);
+    const int k_akkt = scalar_own(a.op.akkt_gradient), k_lsf = scalar_own(a.op.ls_failure), k_help = scalar_own(a.team_help), k_dbg = scalar_own(a.dbg);
     const bool in = t < N, ina = in;            // state layout: lanes beyond the horizon hold zeros
     const bool ine = te < N;                    // evaluation layout: a real stage
     // with a 20-stage horizon every stage lane of the evaluation layout is inside it (lanes 60..63 may
@@ -251,8 +253,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     const double vmin = scalar_own(a.pb.vmin), vmax = scalar_own(a.pb.vmax), wmax = scalar_own(a.pb.wmax);
     const EvK ek = {scalar_own(a.pb.ts), scalar_own(a.inv_ts), scalar_own(a.pb.amin), scalar_own(a.pb.amax), scalar_own(a.pb.awmax)};
     const double tol_ = scalar_own(a.op.tolerance);
-    const unsigned max_inner = (unsigned)a.op.max_inner;
-    const unsigned budget = (unsigned)a.op.max_total_inner;     // 0 = off
+    const unsigned max_inner = (unsigned)scalar_own(a.op.max_inner);
+    const unsigned budget = (unsigned)scalar_own(a.op.max_total_inner);     // 0 = off
     lds_double *Lpar = L + mp.par;
 #define pk_eps_nu Lpar[0]
 #define pk_dy_norm Lpar[1]
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
         // (experiments, scripts/slot_probe.py: first start and migration count travel with the instance; parked in LDS)
         Lpar[13] = (double)__builtin_amdgcn_s_memrealtime(); Lpar[14] = 0.0;
-        if (a.dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+        if (k_dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
         DynStage dyn;
         // (the instance id goes away BEFORE the tables change and comes back after: a helper still evaluating a cancelled request of the previous
@@ -521,10 +523,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 f_begin = false;
                 bool exit_now = false;
                 if (__any(norm_r < tol_)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
-                    if (a.op.akkt_gradient == 2) exit_now = true;
+                    if (k_akkt == 2) exit_now = true;
                     else {
                         const dbl2 q_ = *Lq;
-                        const bool top = a.op.akkt_gradient == 1;       // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
+                        const bool top = k_akkt == 1;       // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
                         const double b1 = top ? (iteration >= 1 ? 0.0 : gv) : gv - q_.x;
                         const double b2 = top ? (iteration >= 1 ? 0.0 : gw) : gw - q_.y;
                         const double a1 = rv / gamma + b1, a2 = rw / gamma + b2;
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     yqw = fma(-0.5, dw, fma(-0.5, rw, uw));
                     need_grad = true; state = D_ITER;
                     // team: idle waves of this workgroup evaluate the trials tau = 2^-2 .. 2^-10 of this direction meanwhile
-                    if (a.team_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
+                    if (k_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
                         if (in && h == 0) { Lreq[t] = dbl2{uv, uw}; Lreq[24 + t] = dbl2{rv, rw}; Lreq[48 + t] = dbl2{dv, dw}; }
                         if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; Lpar[17] = gamma; }
                         team_seq = team_seq >= 0xffff0u ? 1u : team_seq + 1u;
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             // Iteration counts are heavy-tailed: an instance that has already run long is likely the
             // one the whole batch will end up waiting for.  Raise its wave's issue priority so that
             // it runs at (nearly) single-wave speed while it still shares its SIMD with another wave.
-            if (a.dbg == 0 && (n_pass & 1023u) == 0u) {
+            if (k_dbg == 0 && (n_pass & 1023u) == 0u) {
                 const unsigned lvl = n_pass >> 11;
                 if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
                 else if (lvl == 2u) __builtin_amdgcn_s_setprio(2);
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 lhs = NMPC_FBE(pv, pw);                                                \
                 const bool bad_ = __any(lhs > rhs_ls);                                 \
                 rejected = bad_ && ls_n < MAX_LINESEARCH_ITERATIONS;                   \
-                exhausted = bad_ && !rejected && a.op.ls_failure == 1;                 \
+                exhausted = bad_ && !rejected && k_lsf == 1;                 \
                 if (rejected) { tau /= 2.0; ls_n++; }                                  \
             } while (0)
             double lhs = 0.0;
@@ -750,13 +752,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                             dv = rv; dw = rw;                            // empty buffer: d = r
                             rhs_ls = NMPC_FBE(uv, uw) - pk_sigma * nr2;
                             tau = 1.0; ls_n = 0;
-                            if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
+                            if (k_lsf == 1) *Lgk = dbl2{gv, gw};
                             f_trials = true;
                         }
                     } else {
                         lb_first = n_first; lb_head = n_head; lb_active = n_active; pk_H0 = n_H0;      // commit
                         if (n_take_old) { *Los = dbl2{uv, uw}; *Log = dbl2{rv, rw}; }
-                        if (a.op.ls_failure == 1) *Lgk = dbl2{gv, gw};
+                        if (k_lsf == 1) *Lgk = dbl2{gv, gw};
                         NMPC_TAKE_TRIAL(psiB, src1);                     // tau = 1
                         if (rejected) NMPC_TAKE_TRIAL(psiC, src2);       // tau = 1/2
                         if (posted) {
@@ -817,7 +819,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                     pw = fma(-tau, dw, fma(-omt_, rw, uw));
                                     NMPC_HALF_STEP(pv, pw);
                                     lhs = ar[2 * 72 + 4 + jstop];
-                                    exhausted = __any(lhs > rhs_ls) && a.op.ls_failure == 1;      // (only the eleventh trial can stop the search while bad)
+                                    exhausted = __any(lhs > rhs_ls) && k_lsf == 1;      // (only the eleventh trial can stop the search while bad)
                                     rejected = false;
                                 }
                             }
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) pool_push(a, park_cls, inst);
-            if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
+            if (k_dbg == 0) __builtin_amdgcn_s_setprio(0);
             NMPC_WAVE_SYNC();
             continue;
         }
@@ -974,7 +976,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             // first start -> finish on the constant 100 MHz clock (the parked time of a migrated instance included): what the
             // reference reads per solve (src/mpc/mpc_generator.py:214)
             s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - (long long)Lpar[13]) * 1e-5;
-            if (a.dbg) {       // cycles spent on this instance, wave slot, finish time on the 100 MHz reference clock
+            if (k_dbg) {       // cycles spent on this instance, wave slot, finish time on the 100 MHz reference clock
                 s.last_problem_norm_fpr = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
                 s.f2_norm = (double)hw_slot;
                 s.cost = (double)__builtin_amdgcn_s_memrealtime();
@@ -993,13 +995,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #endif
             a.st[inst] = s;
         }
-        if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
+        if (k_dbg == 0) __builtin_amdgcn_s_setprio(0);
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
     }
 
     // ====================================================================== helper: no work of its own (any more)
     // This wave's slice is free now; it holds the result areas, one per (owner, task).
-    if (a.dbg == 0) __builtin_amdgcn_s_setprio(0);
+    if (k_dbg == 0) __builtin_amdgcn_s_setprio(0);
     if (lane == 0) {
         if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
         ctl_add(ctl + CTL_HELPERS, 1);
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     ObsCert oc_h = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate, likewise
     double ws_inst = -1.0;
     for (;;) {
-        if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
+        if (!k_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         // claim the next open task of some sibling's request
         int got = -1;
         if (lane == 0) {

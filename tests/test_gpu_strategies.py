@@ -22,7 +22,8 @@ from mpc_trajectory_generator_amd import named_config
 from mpc_trajectory_generator_amd.solver import BatchSolver
 from mpc_trajectory_generator_amd.harness import synthetic_batch
 from mpc_trajectory_generator_amd.frontend import random_routes
-cfg = named_config("cfg2")
+CFG = os.environ.get("PROBE_CFG", "cfg2")
+cfg = named_config(CFG)
 B = 8192
 P = synthetic_batch(cfg, 11, B, 0, routes=random_routes(cfg, 11, 32, seed=1000))
 scrub = ctypes.CDLL(os.path.join("tests", "scrub", "libscrub.so"))
@@ -48,8 +49,8 @@ print(json.dumps({"kernel": s.kernel_name, "scrub_independent": same(r0, r1), "p
 """
 
 
-def run_probe(lib):
-    env = dict(os.environ)
+def run_probe(lib, config="cfg2"):
+    env = dict(os.environ, PROBE_CFG=config)
     if lib:
         env["NMPC_LIB_PATH"] = lib
     r = subprocess.run([sys.executable, "-c", PROBE], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -71,6 +72,20 @@ def test_two_stage_kernel_same_bits_under_every_scheduler(strategy):
     assert res["sample_equals_oracle"], res
     assert res["permutation_invariant"], res
     assert res["scrub_independent"], res
+
+
+@pytest.mark.parametrize("strategy", ["default", "max-memory-clause", "max-ilp"])
+def test_headline_kernel_has_tested_fallback_strategies(strategy):
+    """The shipped build needs an LLVM-internal scheduler option (iterative-ilp) and a code-generation gate; a toolchain that drops the
+    option or trips the gate must not leave the project without a library.  The HEADLINE kernel (BASELINE config 1) built under the three
+    other strategies passes the gate and gives the same bits -- oracle-exact on a sample, permutation-invariant, scrub-independent --
+    only slower (`make SCHED=...` builds it)."""
+    from mpc_trajectory_generator_amd import _lib
+    check = _lib.build_variant(strategy)
+    assert check.get("ok"), f"code-generation check failed for {strategy}: {check}"
+    res = run_probe(_lib.variant_path(strategy), "cfg1")
+    assert res["kernel"] == "nmpc_solve_hyb_kernel<ShapeDefault>"
+    assert res["sample_equals_oracle"] and res["permutation_invariant"] and res["scrub_independent"], res
 
 
 def test_headline_kernels_do_not_read_what_they_did_not_write():
