@@ -76,7 +76,7 @@ WORKLOADS = {   # what each BASELINE.json configuration is made of (mpc_trajecto
     "cfg3": "configs/default.yaml with Nobs overridden to 50, all slots filled from a synthetic random-polygon circle field",
     "cfg4": "configs/smooth_velocity.yaml's weights/bounds overlaid on default.yaml (N_hor=20), three random moving ellipses per instance",
 }
-POINTS_PER_PASS = {"nmpc_solve_hyb_kernel": 3, "nmpc_solve_hyb2_kernel": 3, "nmpc_solve_dual_kernel": 2, "nmpc_solve_kernel": 1}
+POINTS_PER_PASS = {"nmpc_solve_hyb_kernel": 3, "nmpc_solve_hyb2_kernel": 3, "nmpc_solve_kernel": 1}
 
 
 def flop_model(cfg):

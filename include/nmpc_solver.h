@@ -117,8 +117,8 @@ typedef struct nmpc_status {
     uint32_t reserved;               /* diagnostic: evaluation passes this solve needs in the kernel's schedule --
                                         three query points per pass (nmpc_solve_hyb_kernel, N_hor <= 20; a pass whose
                                         trials were evaluated by helper waves of the team counts like one the owner
-                                        ran itself, so the figure is deterministic), two (nmpc_solve_dual_kernel),
-                                        one (nmpc_solve_kernel<64>: = num_cost_evals + num_grad_evals)      */
+                                        ran itself, so the figure is deterministic; nmpc_solve_hyb2_kernel likewise for
+                                        20 < N_hor <= 40), one (nmpc_solve_kernel<64>: = num_cost_evals + num_grad_evals) */
     double last_problem_norm_fpr;
     double delta_y_norm_over_c;
     double f2_norm;

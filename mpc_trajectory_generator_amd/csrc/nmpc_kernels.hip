@@ -1131,7 +1131,7 @@ namespace nmpc {
 // doubles per parked instance: u, y, previous gradient (2N each) + 16 scalars
 __host__ __device__ inline int park_stride(int N) { return 6 * N + 16; }
 }
-#include "nmpc_solve_dual.h"
+#include "nmpc_solve_common.h"
 #include "nmpc_solve_hyb.h"
 #include "nmpc_solve_hyb2.h"
 #include "nmpc_loop.h"
@@ -1345,7 +1345,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         return NMPC_ERR_NO_DEVICE;
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true; h->last_ms = 0.0;
-    h->P = pb->N <= 20 ? 20 : (pb->N <= 32 ? 32 : (pb->N <= 40 ? 40 : 64));
+    h->P = pb->N <= 20 ? 20 : (pb->N <= 40 ? 40 : 64);      // (the two-point kernel that served 20 < N <= 32 is retired: the two-stage kernel takes those horizons)
     h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
     h->shape_nobs50 = pb->N == nmpc::ShapeNobs50::N && pb->nobs == nmpc::ShapeNobs50::NOBS &&
@@ -1464,7 +1464,7 @@ const char *nmpc_kernel_name(const nmpc_handle *h)
         return h->shape_default ? "nmpc_solve_hyb_kernel<ShapeDefault>"
                                 : (h->shape_nobs50 ? "nmpc_solve_hyb_kernel<ShapeNobs50>" : "nmpc_solve_hyb_kernel<ShapeAny>");
     if (h->P == 40) return h->shape_n40 ? "nmpc_solve_hyb2_kernel<ShapeN40>" : "nmpc_solve_hyb2_kernel<ShapeAny>";
-    return h->P == 32 ? "nmpc_solve_dual_kernel" : "nmpc_solve_kernel<64>";
+    return "nmpc_solve_kernel<64>";
 }
 
 static void fill_args(const nmpc_handle *h, KArgs &a, int B)
@@ -1493,7 +1493,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     a.p = d_p; a.u = d_u; a.y0 = d_y0; a.c0 = d_c0; a.y_out = d_y_out; a.st = d_status;
     HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), s));
     // one instance per wave: N_hor <= 20 evaluates three query points per pass (hybrid / tri layouts),
-    // 20 < N_hor <= 32 two (dual kernel), longer horizons one, with the whole wave as one group
+    // 20 < N_hor <= 40 three with two stages per lane, longer horizons one, with the whole wave as one group
     const int grid = B < h->grid_cap ? B : h->grid_cap;          // waves that take instances
     if (B > grid) {        // more instances than resident waves: hand the hard-looking ones out first
         if (h->use_order) {
@@ -1551,7 +1551,6 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         else if (h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
         else hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
     }
-    else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_solve_dual_kernel, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
@@ -1581,7 +1580,6 @@ int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const doubl
     const int grid = (B + K - 1) / K;
     const size_t lds = (size_t)h->map.total * sizeof(double) * K;
     if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<20>, dim3(grid), dim3(64), lds, s, a);
-    else if (h->P == 32) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<32>, dim3(grid), dim3(64), lds, s, a);
     else hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;

@@ -3,7 +3,7 @@
 //
 // The evaluation of psi runs in the "tri" layout of nmpc_device.h (rows 0..2 of the wave hold stages
 // 0..15 of query points 0..2, the quads of row 3 stages 16..19): three points per pass.  The solver
-// state (u, grad, half step, residual, direction, L-BFGS ring) lives in the layout of the two-point
+// state (u, grad, half step, residual, direction, L-BFGS ring) lives in the two-halves layout (the retired two-point
 // kernel: stage t at lane t of BOTH 32-lane halves, so every reduction of the PANOC / L-BFGS code is a
 // pure DPP + permlane tree (no LDS round trip; the tri layout's row <-> tail exchange costs one per
 // reduction, and the two-loop recursion alone chains twenty of them per iteration).  Query points are
@@ -14,7 +14,7 @@
 //   line search      X = (u+(tau) | u+(tau/2))       Y = u+(tau/4)
 // Trials are consumed in order and the first accepted one ends the iteration, exactly as the
 // sequential line search would; evaluations past the accepted trial are discarded and not counted.
-// Same results and counters as nmpc_solve_dual.h (the two-point kernel) and the sequential oracle.
+// Same results and counters as the sequential oracle.
 //
 // Migration.  With two waves resident per SIMD the hardware serves the older wave slot first: measured on
 // MI355X (scripts/slot_probe.py) a pass costs 5.3 us on wave slot 0 and 6.2-7.1 us on slot 1, whatever

@@ -15,11 +15,12 @@
  *   Every floating-point operation below is written out explicitly (fma() where a fused
  *   multiply-add is meant; the file is compiled with -ffp-contract=off) and all reductions /
  *   scans over the horizon use a fixed, hardware-independent shape:
- *     tree_sum : zero-pad to P (32 for N <= 32, else 64); adjacent-pair binary tree
- *     prefix / suffix sums : Kogge-Stone inside blocks of 16 stages, then block carries; for 32 < N <= 40 the
+ *     tree_sum : zero-pad to P (32 for N <= 20, else 64); adjacent-pair binary tree
+ *     prefix / suffix sums : Kogge-Stone inside blocks of 16 stages, then block carries; for 20 < N <= 40 the
  *                            PAIR form (two consecutive stages are summed first, the Kogge-Stone scan runs over the
  *                            32 pair sums, the first stage of a pair adds its own value to the exclusive result):
  *                            what a kernel that keeps two stages per lane computes (nmpc_solve_hyb2.h)
+ *     quarter dot : the inner products of the Gram-form L-BFGS (N <= 40): qdot() below
  *   so that an implementation on any machine with IEEE-754 f64 add/mul/fma/div/sqrt can
  *   reproduce the results bit for bit.  sin/cos are computed by orc_sincos() (Cody-Waite
  *   reduction + fdlibm kernels written with fma), never by libm.
@@ -91,6 +92,7 @@ void orc_sincos_n(int n, const double *x, double *s, double *c)
 
 /* padded horizon: 32 stages for N <= 32, else 64 */
 static int pad_pow2(int n) { return n <= 32 ? 32 : 64; }
+static int horizon_pad(int N);
 
 /* canonical horizon reduction: adjacent-pair binary tree over P (power of two) entries,
  * ((v0+v1)+(v2+v3))+...; entries >= N are zero.  Destroys v. */
@@ -149,7 +151,7 @@ static void ks_suffix(double *v, int P)
     }
 }
 
-/* PAIR form of the scans (horizons 32 < N <= 40, P = 64):  w_i = v[2i] + v[2i+1];  W = ks_prefix(w) over 32 entries;
+/* PAIR form of the scans (horizons 20 < N <= 40, P = 64):  w_i = v[2i] + v[2i+1];  W = ks_prefix(w) over 32 entries;
  *   prefix[2i+1] = W_i,  prefix[2i] = (i ? W_{i-1} : 0.0) + v[2i];
  * suffix, the mirror image:  Z = ks_suffix(w);  suffix[2i] = Z_i,  suffix[2i+1] = (i < 31 ? Z_{i+1} : 0.0) + v[2i+1]. */
 static void pair_prefix(double *v)
@@ -176,9 +178,11 @@ static void pair_suffix(double *v)
     memcpy(v, out, sizeof(out));
 }
 
-/* the scans of a horizon of N stages padded to P entries */
-static void scan_prefix(double *v, int P, int N) { if (N > 32 && N <= 40) pair_prefix(v); else ks_prefix(v, P); }
-static void scan_suffix(double *v, int P, int N) { if (N > 32 && N <= 40) pair_suffix(v); else ks_suffix(v, P); }
+/* the scans of a horizon of N stages padded to P entries: 20 < N <= 40 is served by the kernel that keeps two stages per lane */
+static void scan_prefix(double *v, int P, int N) { if (N > 20 && N <= 40) pair_prefix(v); else ks_prefix(v, P); }
+static void scan_suffix(double *v, int P, int N) { if (N > 20 && N <= 40) pair_suffix(v); else ks_suffix(v, P); }
+/* padded horizon of a problem: 32 entries for N <= 20 (one stage per lane, three query points per wave), else 64 */
+static int horizon_pad(int N) { return N <= 20 ? 32 : 64; }
 
 /* max/min with the semantics of the IEEE maxNum/minNum the GPU's v_max_f64/v_min_f64 implement,
  * for the non-NaN operands this path produces (second operand is always a finite constant) */
@@ -270,7 +274,7 @@ static void prepare(const orc_problem *pb, const double *p, inst_t *I)
     const int N = pb->N;
     memset(I, 0, sizeof(*I));
     I->N = N;
-    I->P = pad_pow2(N);
+    I->P = horizon_pad(N);
     I->nobs = pb->nobs;
     I->ndyn = pb->ndyn;
     I->ts = pb->ts;
@@ -540,9 +544,9 @@ int orc_eval(const orc_problem *pb, const double *p, const double *u, double c, 
 #define LBFGS_CBFGS_EPSILON 1e-8     /* with cbfgs alpha = 1 */
 
 #define GRAM_M 10      /* pairs the Gram form carries (the hybrid kernel's ring): ages >= m, and inactive ages, are exactly zero */
-/* stages the quarter dot runs over (zero padded): 20 for N <= 20 (nmpc_solve_hyb.h), 40 for 32 < N <= 40 (nmpc_solve_hyb2.h) */
+/* stages the quarter dot runs over (zero padded): 20 for N <= 20 (nmpc_solve_hyb.h), 40 for 20 < N <= 40 (nmpc_solve_hyb2.h) */
 #define GRAM_NST(N) ((N) <= 20 ? 20 : 40)
-#define GRAM_SERVES(N) ((N) <= 20 || ((N) > 32 && (N) <= 40))
+#define GRAM_SERVES(N) ((N) <= 40)
 typedef struct {
     int m, active, first_old;
     int gram;                      /* > 0: the Gram form below, over this many stages (what nmpc_solve_hyb.h / nmpc_solve_hyb2.h compute); 0: the two-loop recursion */
@@ -871,8 +875,8 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
     prepare(pb, p, I);
     const int P = I->P, n2 = pb->nobs + pb->ndyn;
     pc->lb.m = opts->lbfgs_memory;
-    /* the L-BFGS arithmetic follows the kernel that solves this horizon: Gram form for N <= 20 (nmpc_solve_hyb.h) and 32 < N <= 40
-     * (nmpc_solve_hyb2.h), the two-loop recursion otherwise; opts->lbfgs_form = 1 forces the two-loop recursion (tests compare the two) */
+    /* the L-BFGS arithmetic follows the kernel that solves this horizon: Gram form for N <= 40 (nmpc_solve_hyb.h, nmpc_solve_hyb2.h),
+     * the two-loop recursion for the one-point kernel (N > 40); opts->lbfgs_form = 1 forces the two-loop recursion (tests compare the two) */
     pc->lb.gram = (GRAM_SERVES(N) && opts->lbfgs_memory <= GRAM_M && opts->lbfgs_form != 1) ? GRAM_NST(N) : 0;
     hvec u, y, yplus;
     load_hvec(&u, u_io, N, 1);

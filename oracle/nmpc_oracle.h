@@ -62,7 +62,7 @@ typedef struct orc_opts {
     int32_t inner_status;      /* outer criteria hold: 0 report the last inner solve's status,
                                   1 report Converged                                                          */
     int32_t lbfgs_form;        /* ORACLE ONLY (the kernels have one form per horizon): 0 the form of the kernel that solves this
-                                  horizon -- Gram form for N <= 20 and 32 < N <= 40, two-loop recursion otherwise; 1 the two-loop recursion always */
+                                  horizon -- Gram form for N <= 40, two-loop recursion for N > 40; 1 the two-loop recursion always */
 } orc_opts;
 
 typedef struct orc_status {

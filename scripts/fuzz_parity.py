@@ -35,6 +35,6 @@ for case in range(n_cases):
     finally:
         s.close()
     bad += not ok
-    print(f"case {case}: N={N} nobs={nobs} ndyn={ndyn} B={B} {opts} kernel={'hyb' if N <= 20 else ('dual' if N <= 32 else 'one-point')} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {case}: N={N} nobs={nobs} ndyn={ndyn} B={B} {opts} kernel={'hyb' if N <= 20 else ('two-stage' if N <= 40 else 'one-point')} -> {'ok' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad, "of", n_cases)
 sys.exit(1 if bad else 0)

@@ -146,9 +146,7 @@ def test_shape_sweep_bit_exact(N, nobs, ndyn):
                                              ("cfg2", {"NMPC_TEAM_OWNERS": "4"}, "nmpc_solve_hyb2_kernel<ShapeN40>")])
 def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
     """Shapes with a specialised kernel: the run-time-shape kernel must give the same bits on them; the handle reports which
-    kernel runs.  (The two-point kernel is no alternative for N_hor <= 20 any more: the hybrid kernel's L-BFGS is in the Gram
-    form, the oracle follows the kernel that serves the horizon, and the two-point kernel is checked on its own horizons,
-    20 < N_hor <= 32, in the shape sweep.)"""
+    kernel runs.  (The two-point kernel that used to be a third alternative is retired: nmpc_solve_common.h.)"""
     from mpc_trajectory_generator_amd.solver import BatchSolver
     cfg = named_config(name)
     P = synthetic_batch(cfg, 11, 40, 4242, synthetic_circles=(name == "cfg3"))
@@ -163,7 +161,7 @@ def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
 
 
 # restatement switches (include/nmpc_solver.h): every value of every switch, alone and
-# combined, in every solve kernel -- hybrid (N <= 20), dual (20 < N <= 32), two-stage hybrid (32 < N <= 40), one-point (N > 40)
+# combined, in every solve kernel -- hybrid (N <= 20), two-stage hybrid (20 < N <= 40; N = 24 the run-time shape, 40 the specialised one), one-point (N > 40)
 SWITCHES = [dict(akkt_gradient=0), dict(akkt_gradient=2), dict(ls_failure=1), dict(inner_status=1),
             dict(akkt_gradient=0, ls_failure=1, inner_status=1), dict(max_total_inner=150),
             dict(max_total_inner=700, ls_failure=1, akkt_gradient=0), dict(lbfgs_memory=7), dict(lbfgs_memory=2)]
@@ -436,14 +434,14 @@ def test_nonfinite_cost_with_finite_controls_matches_the_oracle(solvers):
         assert not np.all(np.isfinite(gpu[2]["cost"][bad]) & np.isfinite(gpu[2]["last_problem_norm_fpr"][bad]))
 
 
-@pytest.mark.parametrize("name,B", [("cfg1", 4096), ("cfg1", 1), ("cfg2", 512), ("n27-dual", 512)])
+@pytest.mark.parametrize("name,B", [("cfg1", 4096), ("cfg1", 1), ("cfg2", 512), ("n27", 512)])
 def test_per_instance_solve_time(solvers, name, B, monkeypatch):
     """status.solve_time_ms is THIS instance's first-start -> finish time on the device clock (the reference reads
     it per solve, src/mpc/mpc_generator.py:214, and derives its loop overhead from it, src/path_generator.py:387,402-403):
     positive, never above the kernel time of the batch, and growing with the work the instance needed."""
     from mpc_trajectory_generator_amd.solver import BatchSolver
     from mpc_trajectory_generator_amd.config import load_config
-    cfg = load_config(N_hor=27) if name == "n27-dual" else named_config(name)      # (20 < N_hor <= 32: the two-point kernel)
+    cfg = load_config(N_hor=27) if name == "n27" else named_config(name)      # (20 < N_hor <= 32: the run-time-shape two-stage kernel)
     P = synthetic_batch(cfg, 11, B, 31337)
     s = BatchSolver(cfg, max_batch=B)
     try:

@@ -113,9 +113,9 @@ def test_gram_form_lbfgs_is_the_two_loop_recursion(name):
 
 
 def test_lbfgs_form_follows_the_horizon():
-    """N in (20, 32] and N > 40 are served by kernels that run the two-loop recursion: there lbfgs_form changes nothing."""
+    """N > 40 is served by a kernel that runs the two-loop recursion: there lbfgs_form changes nothing."""
     from mpc_trajectory_generator_amd.config import load_config
-    for N in (24, 48):
+    for N in (48, 64):
         cfg = load_config(N_hor=N)
         P = synthetic_batch(cfg, 11, 6, 7)
         a = oracle_for(cfg).solve_batch(P, threads=4)
