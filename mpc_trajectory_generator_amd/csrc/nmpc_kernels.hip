@@ -26,6 +26,7 @@ namespace nmpc {
 constexpr int NZ = 20;         // reference configs/default.yaml:35
 constexpr int MAXMEM = 10;     // L-BFGS memory the kernel is built for
 constexpr int NDYN_MAX = 3;    // Ndynobs the kernel is built for
+constexpr int GRAM_LD = 11;    // row stride of the kept inner products gsy / gyy (doubles): with 10 the ten lanes of a column read hit 8 bank pairs, with 11 ten
 constexpr int GRAM_NST = 20;   // stages the Gram-form L-BFGS of the hybrid kernel runs over (N_hor <= 20, zero padded)
 constexpr int OBS_STRIDE = 4;  // doubles per static circle in LDS: xs ys r^2 r
 constexpr int SEG_STRIDE = 5;  // doubles per reference segment in LDS (odd: the per-lane window gathers of eval_psi spread over all banks)
@@ -175,8 +176,8 @@ __host__ __device__ constexpr LdsMap lds_layout(int N, int nobs, int ndyn, int P
     o = (o + 1) & ~1;                                 // 16-byte alignment for the double2 arrays
     // hybrid kernel: GRAM_NST + 1 columns per slot whatever N is -- the Gram batch reads a slot as GRAM_NST pairs, the last column is
     // all zeros (lanes beyond the horizon read it); gsy | gyy | S | Y are contiguous (zeroed together when the buffer is reset)
-    mp.gsy = o; o += P == 20 ? MAXMEM * MAXMEM : 0;
-    mp.gyy = o; o += P == 20 ? MAXMEM * MAXMEM : 0;
+    mp.gsy = o; o += P == 20 ? MAXMEM * GRAM_LD : 0;
+    mp.gyy = o; o += P == 20 ? MAXMEM * GRAM_LD : 0;
     const int ring = P == 20 ? GRAM_NST + 1 : N;
     mp.S = o;   o += 2 * ring * MAXMEM;
     mp.Y = o;   o += 2 * ring * MAXMEM;

@@ -183,7 +183,7 @@ __device__ __forceinline__ double lane_scalar(double v, int ln)
 #define NMPC_GRAM_BWD(J)                                                                       \
     do {                                                                                       \
         const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J);        \
-        const double gr_ = Lgsy[pj_ * MAXMEM + pk_];                                           \
+        const double gr_ = Lgsy[pj_ * GRAM_LD + pk_];                                           \
         const dbl2 sp_ = LS[pj_ * NS + tt];                                                    \
         const double be_ = rho_k * ga2;                                                        \
         const double ab_ = alv - be_;                                                          \
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #define NMPC_LB_ZERO()                                                                                  \
     do {                                                                                                \
         lds_double2 *z_ = (lds_double2 *)(L + mp.gsy);                                                  \
-        for (int i_ = lane; i_ < MAXMEM * MAXMEM + 2 * MAXMEM * NS; i_ += 64) z_[i_] = dbl2{0.0, 0.0};  \
+        for (int i_ = lane; i_ < MAXMEM * GRAM_LD + 2 * MAXMEM * NS; i_ += 64) z_[i_] = dbl2{0.0, 0.0};  \
         if (lane < MAXMEM) Lrho[lane] = 0.0;                                                            \
     } while (0)
     if (threadIdx.x < TEAM_CTL_INTS) ctl[threadIdx.x] = threadIdx.x == CTL_OWNERS ? a.team_owners : 0;
@@ -565,10 +565,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                             // own row of gsy is zero (gsy is strictly lower triangular by age), and so is the diagonal
                             if (c16 < MAXMEM && q4 < 3) {
                                 const bool dg = c16 == n_head;
-                                lds_double *wa = q4 == 0 ? Lgsy + c16 * MAXMEM + n_head : (q4 == 1 ? Lgsy + n_head * MAXMEM + c16 : Lgyy + c16 * MAXMEM + n_head);
+                                lds_double *wa = q4 == 0 ? Lgsy + c16 * GRAM_LD + n_head : (q4 == 1 ? Lgsy + n_head * GRAM_LD + c16 : Lgyy + c16 * GRAM_LD + n_head);
                                 const double wv = q4 == 1 ? 0.0 : (dg ? (q4 == 0 ? 0.0 : yy) : gU);
                                 *wa = wv;
-                                if (q4 == 2) Lgyy[n_head * MAXMEM + c16] = wv;
+                                if (q4 == 2) Lgyy[n_head * GRAM_LD + c16] = wv;
                             }
                             if (m < MAXMEM) {
                                 // a shorter memory (opts.lbfgs_memory < 10): the pair that has just reached age m leaves -- its slot goes back
@@ -577,8 +577,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                 if (t <= GRAM_NST && h == 0) { LS[ev * NS + t] = dbl2{0.0, 0.0}; LY[ev * NS + t] = dbl2{0.0, 0.0}; }
                                 if (lane == 0) Lrho[ev] = 0.0;
                                 if (c16 < MAXMEM && q4 < 2) {
-                                    (q4 == 0 ? Lgsy : Lgyy)[c16 * MAXMEM + ev] = 0.0;
-                                    (q4 == 0 ? Lgsy : Lgyy)[ev * MAXMEM + c16] = 0.0;
+                                    (q4 == 0 ? Lgsy : Lgyy)[c16 * GRAM_LD + ev] = 0.0;
+                                    (q4 == 0 ? Lgsy : Lgyy)[ev * GRAM_LD + c16] = 0.0;
                                 }
                             }
                         }
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     if (n_active > 0) {
                         // age k = lane & 15 of every row (lanes 10..15 idle along on slot 9; what they compute is never looked at)
                         const int pk_ = c16 < MAXMEM ? (n_head + c16 >= MAXMEM ? n_head + c16 - MAXMEM : n_head + c16) : MAXMEM - 1;
-                        const int pkrow = pk_ * MAXMEM;
+                        const int pkrow = pk_ * GRAM_LD;
                         double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
                         if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }      // (the ring held the evicted pair)
                         const double rho_k = Lrho[pk_];

@@ -116,8 +116,8 @@ __host__ __device__ constexpr LdsMap2 lds_layout2(int N, int nobs, int ndyn)
     mp.f2 = mp.vec;
     if (7 * H2_COLS * 4 < 3 * (nobs + ndyn + 1)) o = mp.vec + 3 * (nobs + ndyn + 1);
     o = (o + 1) & ~1;
-    mp.gsy = o; o += MAXMEM * MAXMEM;   // gsy | gyy | S | Y are contiguous (zeroed together when the buffer is reset)
-    mp.gyy = o; o += MAXMEM * MAXMEM;
+    mp.gsy = o; o += MAXMEM * GRAM_LD;   // gsy | gyy | S | Y are contiguous (zeroed together when the buffer is reset)
+    mp.gyy = o; o += MAXMEM * GRAM_LD;
     mp.S = o;   o += MAXMEM * H2_NS * 4;
     mp.Y = o;   o += MAXMEM * H2_NS * 4;
     // (the four vectors live from the top of a pass to the end of its L-BFGS phase; the query points and gradients of the pass, which are
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 #define NMPC2_LB_ZERO()                                                                                    \
     do {                                                                                                   \
         lds_double2 *z_ = (lds_double2 *)(L + mp.gsy);                                                     \
-        for (int i_ = lane; i_ < MAXMEM * MAXMEM + 4 * MAXMEM * H2_NS; i_ += 64) z_[i_] = dbl2{0.0, 0.0};  \
+        for (int i_ = lane; i_ < MAXMEM * GRAM_LD + 4 * MAXMEM * H2_NS; i_ += 64) z_[i_] = dbl2{0.0, 0.0};  \
         if (lane < MAXMEM) Lrho[lane] = 0.0;                                                               \
     } while (0)
     lds_double2 *LS = (lds_double2 *)(L + mp.S);
@@ -883,18 +883,18 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             if (n_active < m) n_active++;
                             if (c16 < MAXMEM && q4 < 3) {
                                 const bool dg = c16 == n_head;
-                                lds_double *wa = q4 == 0 ? Lgsy + c16 * MAXMEM + n_head : (q4 == 1 ? Lgsy + n_head * MAXMEM + c16 : Lgyy + c16 * MAXMEM + n_head);
+                                lds_double *wa = q4 == 0 ? Lgsy + c16 * GRAM_LD + n_head : (q4 == 1 ? Lgsy + n_head * GRAM_LD + c16 : Lgyy + c16 * GRAM_LD + n_head);
                                 const double wv = q4 == 1 ? 0.0 : (dg ? (q4 == 0 ? 0.0 : yy) : gU);
                                 *wa = wv;
-                                if (q4 == 2) Lgyy[n_head * MAXMEM + c16] = wv;
+                                if (q4 == 2) Lgyy[n_head * GRAM_LD + c16] = wv;
                             }
                             if (m < MAXMEM) {      // a shorter memory: the pair that has just reached age m leaves, its slot goes back to zeros
                                 const int ev = n_head + m >= MAXMEM ? n_head + m - MAXMEM : n_head + m;
                                 if (t < H2_NS && h == 0) { st4<H2_NS>(LS + 2 * H2_NS * (ev), t, d2s(0.0), d2s(0.0)); st4<H2_NS>(LY + 2 * H2_NS * (ev), t, d2s(0.0), d2s(0.0)); }
                                 if (lane == 0) Lrho[ev] = 0.0;
                                 if (c16 < MAXMEM && q4 < 2) {
-                                    (q4 == 0 ? Lgsy : Lgyy)[c16 * MAXMEM + ev] = 0.0;
-                                    (q4 == 0 ? Lgsy : Lgyy)[ev * MAXMEM + c16] = 0.0;
+                                    (q4 == 0 ? Lgsy : Lgyy)[c16 * GRAM_LD + ev] = 0.0;
+                                    (q4 == 0 ? Lgsy : Lgyy)[ev * GRAM_LD + c16] = 0.0;
                                 }
                             }
                         }
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     dv = rv; dw = rw;
                     if (n_active > 0) {
                         const int pk_ = c16 < MAXMEM ? (n_head + c16 >= MAXMEM ? n_head + c16 - MAXMEM : n_head + c16) : MAXMEM - 1;
-                        const int pkrow = pk_ * MAXMEM;
+                        const int pkrow = pk_ * GRAM_LD;
                         double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
                         if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }
                         const double rho_k = Lrho[pk_];
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 #define NMPC2_GRAM_BWD(J)                                                                          \
                         do {                                                                       \
                             const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J); \
-                            const double gr_ = Lgsy[pj_ * MAXMEM + pk_];                           \
+                            const double gr_ = Lgsy[pj_ * GRAM_LD + pk_];                           \
                             D2 s1_, s2_;                                                           \
                             ld4<H2_NS>(LS + 2 * H2_NS * (pj_), tt, s1_, s2_);                      \
                             const double be_ = rho_k * ga2;                                        \
