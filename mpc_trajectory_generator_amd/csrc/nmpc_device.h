@@ -66,7 +66,7 @@ __device__ __forceinline__ int lane_get_i(int v, int src_lane)
 // registers.  They are never handed the same value twice (swap(x, x)): ROCm 7.2's register coalescer then joins the copy with x into one
 // wide virtual register and leaves a read-undef flag on the swap's tied second def that declares the other lanes of x dead, and a
 // scheduler that moves the copy above the instruction producing x (-amdgpu-sched-strategy=max-ilp does) swaps a stale register -- wrong
-// results that depend on what ran before (scripts/check_sched.py finds both the flag and the move).  Instead the
+// results that depend on what ran before (codegen_check.py finds both the flag and the move).  Instead the
 // second register is a full 64-bit definition of its own: the producing addition issued twice (one v_add_f64 instead of the two v_mov_b32
 // of a copy -- `opaque` keeps the compiler from merging them), or an opaque copy where there is no producing instruction to repeat.
 __device__ __forceinline__ double opaque(double x)

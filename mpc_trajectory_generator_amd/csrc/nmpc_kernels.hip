@@ -316,10 +316,7 @@ __device__ __forceinline__ unsigned long long circle_near_mask(const double *p, 
 // ---------------------------------------------------------------------------------------------
 // psi(z; c, y), grad psi, F1 (av, aw), sum_k F2_k^2 (pen); WRITE_F2: F2_k also left in the LDS slice
 // ---------------------------------------------------------------------------------------------
-#ifdef NMPC_PROFILE
-#define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_evt[i] += t_ - nmpc_evl; nmpc_evl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-__device__ long long nmpc_dummy_;
-#elif defined(NMPC_PROF2) && NMPC_PROF2 == 2      // scripts/sections.py: cycles of the evaluation by section, accumulated in registers of the caller
+#if defined(NMPC_PROF2) && NMPC_PROF2 == 2      // scripts/sections.py: cycles of the evaluation by section, accumulated in registers of the caller
 #define NMPC_EVTICK(i) do { if (nmpc_pe) { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); nmpc_pe[i] += t_ - nmpc_pe[7]; nmpc_pe[7] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #elif defined(NMPC_MARKS)       // scripts/isa_stats.py: section markers in the ISA dump
 #define NMPC_EVTICK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -362,11 +359,6 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     constexpr bool FULL = P == 20 && SH::N == 20;
     const bool in_r = t < N;                    // a real stage
     const bool in = FULL ? true : in_r;         // arithmetic masks: compile-time true when FULL
-#ifdef NMPC_PROFILE
-    extern __shared__ long long nmpc_prof_lds[];
-    long long *nmpc_evt = nmpc_prof_lds + 4096 + (threadIdx.x == 0 ? 0 : 8);   // lane 0 accumulates; others to a dummy row
-    long long nmpc_evl = __builtin_amdgcn_s_memtime();
-#endif
     const lds_double *sc = L + mp.sc;
     const double x0 = sc[SC_X0], y0 = sc[SC_Y0], th0 = sc[SC_TH0];
     const double xf = sc[SC_XF], yf = sc[SC_YF], thf = sc[SC_THF];
@@ -1519,11 +1511,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
             a.sched_mode = h->sched_mode;
         }
     }
-#ifdef NMPC_PROFILE
-    const size_t lds = 4096 * 8 + 256;
-#else
     const size_t lds = (size_t)h->map.total * sizeof(double);
-#endif
     if (h->P == 20 || h->P == 40) {
         // teams of four waves.  With fewer instances than workgroups fit on the chip every instance gets a workgroup of its
         // own (one wave solves, three help from the first iteration on: the small-batch / latency mode); otherwise as many
@@ -1539,11 +1527,7 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         a.sched_cold_cap = (int)(h->sched_cold * (double)(wgs * owners));
         a.team_help = h->team_help;
         a.cull_radius = h->cull_radius;
-#ifdef NMPC_PROFILE
-        const size_t tlds = lds;
-#else
         const size_t tlds = h->team_lds;
-#endif
         if (h->P == 40) {
             if (h->shape_n40) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeN40>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
             else hipLaunchKernelGGL(nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeAny>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);

@@ -17,7 +17,7 @@
 // Same results and counters as the sequential oracle.
 //
 // Migration.  With two waves resident per SIMD the hardware serves the older wave slot first: measured on
-// MI355X (scripts/slot_probe.py) a pass costs 5.3 us on wave slot 0 and 6.2-7.1 us on slot 1, whatever
+// MI355X (round 4, profiles/r04/DESIGN_round4.md section 5.5) a pass costs 5.3 us on wave slot 0 and 6.2-7.1 us on slot 1, whatever
 // s_setprio says, and a batch ends when its slowest instance does.  So an instance that has already run
 // `park_min` passes on an unfavoured wave is PARKED at its next outer-iteration boundary (the state there is
 // small: u, y, the previous gradient and a dozen scalars) and pushed to a pool; favoured waves look into the
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         if (inst < 0) break;     // nothing left for this wave: a helper from now on
 
         const long long dbg_t0 = __builtin_amdgcn_s_memtime();
-        // (experiments, scripts/slot_probe.py: first start and migration count travel with the instance; parked in LDS)
+        // (experiments, NMPC_DEBUG_PRIO: first start and migration count travel with the instance; parked in LDS)
         Lpar[13] = (double)__builtin_amdgcn_s_memrealtime(); Lpar[14] = 0.0;
         if (k_dbg == 1) { if (hw_slot & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
         double vref_;
@@ -658,8 +658,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             double psi, pen, egv = 0, egw = 0, eav, eaw;
             n_pass++;
             // Iteration counts are heavy-tailed: an instance that has already run long is likely the
-            // one the whole batch will end up waiting for.  Raise its wave's issue priority so that
-            // it runs at (nearly) single-wave speed while it still shares its SIMD with another wave.
+            // one the whole batch will end up waiting for.  Raise its wave's issue priority while it shares its SIMD with another
+            // wave: worth 1-2 % of the headline batch (39.2 against 39.9 ms without; levels at 1k / 2k / 3k or 0.5k / 1k / 1.5k passes
+            // instead of 2k / 4k / 6k: the same within noise) -- the older wave slot is still served first (top of the file).
             if (k_dbg == 0 && (n_pass & 1023u) == 0u) {
                 const unsigned lvl = n_pass >> 11;
                 if (lvl == 1u) __builtin_amdgcn_s_setprio(1);

@@ -739,10 +739,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             nu = (int)pks[8]; inner_total = (unsigned)pks[9]; n_cost = (unsigned)pks[10]; n_grad = (unsigned)pks[11]; n_pass = (unsigned)pks[12];
             t_start = (long long)pks[13]; long_counted = pks[15] != 0.0; q_pass = n_pass;
         }
-#ifdef NMPC2_TICKS      // scripts/hyb2_sections.py: s_memtime ticks per section of a pass (fenced: upper bounds), reported in the status reals
-        long long tk[5] = {0, 0, 0, 0, 0}, tkl = __builtin_amdgcn_s_memtime();
-#define NMPC2_TK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); tk[((i) + 4) % 5] += t_ - tkl; tkl = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(NMPC_MARKS)  // section markers in the ISA dump (hipcc -S -DNMPC_MARKS)
+#if defined(NMPC_MARKS)     // section markers in the ISA dump (hipcc -S -DNMPC_MARKS; scripts/isa_stats.py)
 #define NMPC2_TK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " #i); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define NMPC2_TK(i) do { } while (0)
@@ -1270,13 +1267,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
             s.penalty = pen_c;
             s.cost = last_cost;
             s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - t_start) * 1e-5;
-            if (a.dbg) {       // experiments (NMPC_DEBUG_PRIO, scripts/slot_probe.py): start and finish on the 100 MHz clock, workgroup and wave
+            if (a.dbg) {       // experiments (NMPC_DEBUG_PRIO, scripts/utilisation.py): start and finish on the 100 MHz clock, workgroup and wave
                 s.delta_y_norm_over_c = (double)t_start; s.cost = (double)(long long)__builtin_amdgcn_s_memrealtime();
                 s.f2_norm = (double)(blockIdx.x * TEAM_WAVES + wid);
             }
-#ifdef NMPC2_TICKS
-            s.last_problem_norm_fpr = (double)tk[4]; s.delta_y_norm_over_c = (double)tk[0]; s.f2_norm = (double)tk[1]; s.penalty = (double)tk[2]; s.cost = (double)tk[3];
-#endif
             a.st[inst] = s;
         }
         NMPC_WAVE_SYNC();          // the LDS slice is reused by the next instance
