@@ -270,6 +270,20 @@ struct WinState {
     int ctr;
     double xr, yr, mo2;
 };
+// -DNMPC_TL (scripts/timeline.py): s_memtime of fifteen events of a helped iteration -- owner 0..10, the helper of its first task 11..14 --
+// for 64 consecutive iterations of the instance that runs them (one instance solved alone)
+#ifdef NMPC_TL
+__device__ long long nmpc_tl[64 * 16];
+#ifdef NMPC_MARKS      // (with -DNMPC_MARKS: the events as markers in the ISA dump instead)
+#define NMPC_TL_EV(it, ev) do { (void)(it); __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK TL_" #ev); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NMPC_TL_EV(it, ev) do { if ((it) >= 200 && (it) < 264 && lane == 0) nmpc_tl[((it) - 200) * 16 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
+#define NMPC_TL_KEEP(x) do { double keep_ = (x); asm volatile("" : "+v"(keep_)); } while (0)
+#else
+#define NMPC_TL_EV(it, ev) do { } while (0)
+#define NMPC_TL_KEEP(x) do { } while (0)
+#endif
 #ifdef NMPC_WIN_STATS
 __device__ unsigned long long nmpc_win_stats[4];       // evaluations that tried the window | of which fell back to the full scan | that tried the obstacle certificate | of which scanned
 #endif
@@ -1951,6 +1965,10 @@ int nmpc_test_divsqrt_host(nmpc_handle *h, int n, const double *a, const double 
     return run_unary_test(h, n, a, b, out_div, out_sqrt, 1);
 }
 
+#ifdef NMPC_TL
+// experiments only (scripts/timeline.py)
+int nmpc_debug_timeline(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmpc::nmpc_tl), 64 * 16 * sizeof(long long)) == hipSuccess ? NMPC_OK : NMPC_ERR_HIP; }
+#endif
 #ifdef NMPC_WIN_STATS
 // experiments only (scripts/win_stats.py): windowed cross-track searches and how many of them fell back to the full scan
 int nmpc_debug_win_stats(unsigned long long *out, int reset)

@@ -142,11 +142,6 @@ __device__ __forceinline__ int pool_depth(const KArgs &a, int c)
 // and the direction is updated with them as the two-loop recursion would.  Measured (scripts/ubench/mfma_f64.hip): v_mfma_f64_4x4x4
 // shares the f64 pipe with the vector ALU (17 cycles = 4 v_fma_f64) and is an exact ascending fma chain over k, but for this shape
 // it would compute four times the products the lanes need -- so the batch is plain v_fma_f64.
-template <int J>
-__device__ __forceinline__ double row_bcast_lane(double x)       // lane J of this lane's row (one v_mov_b64_dpp)
-{
-    return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + J, 0xF, 0xF, false);
-}
 // acc - x[lane J of the row] * y in ONE instruction (the recurrences' critical path); the two wait states a DPP read of a fresh VALU
 // result needs are spelled out, the compiler does not see into the statement
 template <int J>
@@ -160,6 +155,46 @@ __device__ __forceinline__ double fma_row_bcast(double acc, double x, double y)
 {
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
     return acc;
+}
+// the same broadcast folded into the updates that FOLLOW a recurrence step (no v_mov_b64_dpp, no register for the broadcast value).  They
+// carry no wait states of their own: `after` -- the step's own result, which read x through DPP two wait states after x was written -- orders
+// them behind it.
+template <int J>
+__device__ __forceinline__ void fnma3_row_bcast(double &a1, double &a2, double &a3, double x, double y1, double y2, double y3, double after)
+{
+    asm("v_fmac_f64_dpp %0, -%3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, -%3, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, -%3, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y1), "v"(y2), "v"(y3), "v"(after), "n"(J));
+}
+template <int J>
+__device__ __forceinline__ void fma2_row_bcast(double &a1, double &a2, double x, double y1, double y2, double after)
+{
+    asm("v_fmac_f64_dpp %0, %2, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+        : "+v"(a1), "+v"(a2) : "v"(x), "v"(y1), "v"(y2), "v"(after), "n"(J));
+}
+// (the two-stage kernel's: two stages per lane)
+template <int J>
+__device__ __forceinline__ void fnma5_row_bcast(double &a1, double &a2, double &a3, double &a4, double &a5, double x, double y1, double y2, double y3,
+                                                double y4, double y5, double after)
+{
+    asm("v_fmac_f64_dpp %0, -%5, %6 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, -%5, %7 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, -%5, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, -%5, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, -%5, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+        : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "v"(x), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(y5), "v"(after), "n"(J));
+}
+template <int J>
+__device__ __forceinline__ void fma4_row_bcast(double &a1, double &a2, double &a3, double &a4, double x, double y1, double y2, double y3, double y4,
+                                               double after)
+{
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+        : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "v"(x), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(after), "n"(J));
 }
 // the value lane `ln` (a constant) holds, as a wave-uniform scalar
 __device__ __forceinline__ double lane_scalar(double v, int ln)
@@ -176,9 +211,7 @@ __device__ __forceinline__ double lane_scalar(double v, int ln)
         const dbl2 yp_ = LY[pj_ * NS + tt];                                                    \
         const double al_ = rho_k * ga1;                                                        \
         ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                                              \
-        const double bc_ = row_bcast_lane<(J)>(al_);                                           \
-        ga2 = fma(-bc_, gy_, ga2);                                                             \
-        dv = fma(-bc_, yp_.x, dv); dw = fma(-bc_, yp_.y, dw);                                  \
+        fnma3_row_bcast<(J)>(ga2, dv, dw, al_, gy_, yp_.x, yp_.y, ga1);                        \
     } while (0)
 #define NMPC_GRAM_BWD(J)                                                                       \
     do {                                                                                       \
@@ -188,8 +221,7 @@ __device__ __forceinline__ double lane_scalar(double v, int ln)
         const double be_ = rho_k * ga2;                                                        \
         const double ab_ = alv - be_;                                                          \
         ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                                               \
-        const double bc_ = row_bcast_lane<(J)>(ab_);                                           \
-        dv = fma(bc_, sp_.x, dv); dw = fma(bc_, sp_.y, dw);                                    \
+        fma2_row_bcast<(J)>(dv, dw, ab_, sp_.x, sp_.y, ga2);                                   \
     } while (0)
 
 template <class SH>
@@ -402,6 +434,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
         bool running = true, timed_out = false;
         bool posted = false;                      // a request of the current iteration is open for the helpers
+#ifdef NMPC_TL
+        int tl_it = 0;                            // PANOC steps of this instance so far
+#endif
         // -DNMPC_PROF2 (scripts/sections.py): cycles of this instance by section of the loop -- 0 phase handlers in front of the batch, 1 the batch
         // of inner products, 2 exit test / L-BFGS update, 3 the recurrences and the direction, 4 envelope, trial points, request, 5 the
         // evaluation, 6 the consumption of the trials.  Every mark drains the LDS queue, so the sum is a little above the plain build's time.
@@ -470,6 +505,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             }
             // ---------------------------------------------------------------- start of a PANOC step
             if (f_begin) { rv = uv - hv; rw = uw - hw; lb_batch = true; }
+#ifdef NMPC_TL
+            if (f_begin) { tl_it++; NMPC_TL_EV(tl_it, 0); }
+#endif
             NMPC_SEC(pf0);
             // ---- the batch of inner products of this step (Gram-form L-BFGS, see the top of the file)
             double gU = 0.0, gs1 = 0.0, gs2 = 0.0, gy1 = 0.0, gy2 = 0.0;
@@ -514,6 +552,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #endif
             }
             NMPC_SEC(pf1);
+#ifdef NMPC_TL
+            if (lb_batch) { NMPC_TL_KEEP(norm_r + gU); NMPC_TL_EV(tl_it, 1); }
+#endif
             if (f_back) {
                 f_back = false;
                 lip_it++;
@@ -585,6 +626,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     }
                     // ---- d = H r over the tentative buffer ----
                     dv = rv; dw = rw;
+#ifdef NMPC_TL
+                    NMPC_TL_EV(tl_it, 2);
+#endif
                     NMPC_SEC(pf2);
                     if (n_active > 0) {
                         // age k = lane & 15 of every row (lanes 10..15 idle along on slot 9; what they compute is never looked at)
@@ -604,6 +648,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #ifdef NMPC_PROF2
                     { double keep = dv + dw; asm volatile("" : "+v"(keep)); }
 #endif
+#ifdef NMPC_TL
+                    NMPC_TL_KEEP(dv + dw); NMPC_TL_EV(tl_it, 3);
+#endif
                     NMPC_SEC(pf3);
                     if (!fbe_ok) { pk_fbe_u = NMPC_FBE(uv, uw); fbe_ok = true; }
                     rhs_ls = pk_fbe_u - pk_sigma * nr2;
@@ -617,10 +664,17 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     if (k_help && __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_HELPERS)) > 0) {
                         if (in && h == 0) { Lreq[t] = dbl2{uv, uw}; Lreq[24 + t] = dbl2{rv, rw}; Lreq[48 + t] = dbl2{dv, dw}; }
                         if (lane == 0) { Lpar[15] = pen_c; Lpar[16] = cbar_inv; Lpar[17] = gamma; }
+#ifdef NMPC_TL
+                        if (lane == 0) Lpar[22] = (double)tl_it;
+                        NMPC_TL_EV(tl_it, 4);
+#endif
                         team_seq = team_seq >= 0xffff0u ? 1u : team_seq + 1u;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __builtin_amdgcn_wave_barrier();
                         if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, (int)(team_seq << 8));
+#ifdef NMPC_TL
+                        NMPC_TL_EV(tl_it, 5);
+#endif
                         posted = true;
                     }
                 }
@@ -668,6 +722,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 else if (lvl >= 3u) __builtin_amdgcn_s_setprio(3);
             }
             NMPC_SEC(pf4);
+#ifdef NMPC_TL
+            if (state == D_ITER) NMPC_TL_EV(tl_it, 6);
+#endif
 #ifdef NMPC_MARKS
             asm volatile("; MARK 10");
 #endif
@@ -687,6 +744,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
 #endif
             NMPC_SEC(pf5);
+#ifdef NMPC_TL
+            if (state == D_ITER) { NMPC_TL_KEEP(psi + egv); NMPC_TL_EV(tl_it, 7); }
+#endif
 #ifdef NMPC_MARKS
             asm volatile("; MARK 11");
 #endif
@@ -762,71 +822,90 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                         if (k_lsf == 1) *Lgk = dbl2{gv, gw};
                         NMPC_TAKE_TRIAL(psiB, src1);                     // tau = 1
                         if (rejected) NMPC_TAKE_TRIAL(psiC, src2);       // tau = 1/2
+#ifdef NMPC_TL
+                        NMPC_TL_KEEP(lhs + hv); NMPC_TL_EV(tl_it, 8);
+#endif
                         if (posted) {
                             // tasks 0..2 of the request hold trials ls_n = 2 + 3k .. 4 + 3k.  A task a helper has claimed is
                             // waited for and consumed in order; the first one nobody has claimed is closed (with everything
                             // after it) and this wave goes on by itself, as it would without a team.
-                            const lds_double2 *prev_ag = nullptr;        // gradient of the last trial a helper's area rejected
+                            bool have_prev = false;                      // prev_g: gradient of the last trial a helper's area rejected
+                            dbl2 prev_g = dbl2{0.0, 0.0};
                             for (int k = 0; k < 3 && rejected; ++k) {
                                 int hid = -1;
-                                if (lane == 0) {
-                                    lds_int *cl = ctl + CTL_CLAIM + wid;
-                                    bool served = false;
-                                    for (;;) {
-                                        int v = ctl_load(cl);
-                                        if ((v & 0xff) > k) { served = true; break; }
-                                        if (__hip_atomic_compare_exchange_strong(cl, &v, (int)(team_seq << 8) | 3, __ATOMIC_RELAXED,
-                                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-                                    }
-                                    if (served) {
-                                        lds_int *dn = ctl + CTL_DONE + (wid * 3 + k) * TEAM_WAVES;
+                                lds_int *dn = ctl + CTL_DONE + (wid * 3 + k) * TEAM_WAVES;
+                                {   // first look, ONE LDS read for the task's four done flags: by now the helper has usually finished
+                                    // (its flag is up 600 cycles before this wave is through with its own two trials)
+                                    const int fl_ = lane < TEAM_WAVES ? ctl_load(dn + lane) : 0;
+                                    const unsigned long long dm_ = __ballot(lane < TEAM_WAVES && fl_ == (int)team_seq);
+                                    if (dm_ != 0ull) hid = __builtin_ctzll(dm_);
+                                }
+                                if (hid < 0) {
+                                    if (lane == 0) {
+                                        lds_int *cl = ctl + CTL_CLAIM + wid;
+                                        bool served = false;
                                         for (;;) {
+                                            int v = ctl_load(cl);
+                                            if ((v & 0xff) > k) { served = true; break; }
+                                            if (__hip_atomic_compare_exchange_strong(cl, &v, (int)(team_seq << 8) | 3, __ATOMIC_RELAXED,
+                                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                                        }
+                                        if (served) {
+                                            for (;;) {
 #pragma unroll
-                                            for (int w2 = 0; w2 < TEAM_WAVES; ++w2) if (ctl_load(dn + w2) == (int)team_seq) hid = w2;
-                                            if (hid >= 0) break;
-                                            __builtin_amdgcn_s_sleep(1);
+                                                for (int w2 = 0; w2 < TEAM_WAVES; ++w2) if (ctl_load(dn + w2) == (int)team_seq) hid = w2;
+                                                if (hid >= 0) break;
+                                                __builtin_amdgcn_s_sleep(1);
+                                            }
                                         }
                                     }
+                                    hid = __builtin_amdgcn_readfirstlane(hid);
                                 }
-                                hid = __builtin_amdgcn_readfirstlane(hid);
+#ifdef NMPC_TL
+                                if (k == 0) NMPC_TL_EV(tl_it, 9);
+#endif
                                 if (hid < 0) break;
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                                 n_pass++;                                // the pass these three trials would have cost this wave
                                 // The helper has formed each trial's envelope value too (same canonical sums), so the sequential
-                                // decision over its three trials is three comparisons; only the trial the search stops at -- accepted,
-                                // or the eleventh -- is loaded into the solver state.
+                                // decision over its three trials is three comparisons.  Values and gradients of all three come in with
+                                // the envelopes -- one LDS round trip instead of two on the critical path of a helped iteration.
                                 const lds_double *ar = (const lds_double *)lds + hid * slice + (wid * 3 + k) * TEAM_AREA_DOUBLES;
                                 const lds_double2 *ag = (const lds_double2 *)ar + (in ? t : 0);
+                                const dbl2 g0_ = ag[0], g1_ = ag[24], g2_ = ag[48];
+                                const double c0_ = ar[2 * 72], c1_ = ar[2 * 72 + 1], c2_ = ar[2 * 72 + 2];
+                                const double l0_ = ar[2 * 72 + 4], l1_ = ar[2 * 72 + 5], l2_ = ar[2 * 72 + 6];
                                 int jstop = 3;
-#pragma unroll
-                                for (int j = 2; j >= 0; --j) {
-                                    const bool rej_j = __any(ar[2 * 72 + 4 + j] > rhs_ls) && ls_n + j < MAX_LINESEARCH_ITERATIONS;
-                                    if (!rej_j) jstop = j;               // ends as the FIRST trial that is not rejected
-                                }
+                                if (!(__any(l2_ > rhs_ls) && ls_n + 2 < MAX_LINESEARCH_ITERATIONS)) jstop = 2;
+                                if (!(__any(l1_ > rhs_ls) && ls_n + 1 < MAX_LINESEARCH_ITERATIONS)) jstop = 1;
+                                if (!(__any(l0_ > rhs_ls) && ls_n < MAX_LINESEARCH_ITERATIONS)) jstop = 0;      // ends as the FIRST trial that is not rejected
                                 if (jstop == 3) {                        // all three rejected: on to the next task
                                     n_grad += 3; ls_n += 3; tau *= 0.125;
-                                    prev_ag = ag + 24 * 2;
+                                    have_prev = true; prev_g = g2_;
                                 } else {
                                     n_grad += (unsigned)jstop + 1u; ls_n += jstop;
                                     tau *= jstop == 0 ? 1.0 : (jstop == 1 ? 0.5 : 0.25);
                                     // cache_previous_gradient: the gradient of the trial before the one that stops the search
-                                    if (jstop > 0) prev_ag = ag + 24 * (jstop - 1);
-                                    if (prev_ag) { const dbl2 g_ = *prev_ag; *Lq = dbl2{in ? g_.x : 0.0, in ? g_.y : 0.0}; }
+                                    if (jstop > 0) { have_prev = true; prev_g = jstop == 1 ? g0_ : g1_; }
+                                    if (have_prev) *Lq = dbl2{in ? prev_g.x : 0.0, in ? prev_g.y : 0.0};
                                     else *Lq = dbl2{gv, gw};
-                                    cost = ar[2 * 72 + jstop];
-                                    { const dbl2 g_ = ag[24 * jstop]; gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0; }
+                                    cost = jstop == 0 ? c0_ : (jstop == 1 ? c1_ : c2_);
+                                    { const dbl2 g_ = jstop == 0 ? g0_ : (jstop == 1 ? g1_ : g2_); gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0; }
                                     const double omt_ = 1.0 - tau;
                                     pv = fma(-tau, dv, fma(-omt_, rv, uv));
                                     pw = fma(-tau, dw, fma(-omt_, rw, uw));
                                     NMPC_HALF_STEP(pv, pw);
-                                    lhs = ar[2 * 72 + 4 + jstop];
+                                    lhs = jstop == 0 ? l0_ : (jstop == 1 ? l1_ : l2_);
                                     exhausted = __any(lhs > rhs_ls) && k_lsf == 1;      // (only the eleventh trial can stop the search while bad)
                                     rejected = false;
                                 }
                             }
-                            if (rejected && prev_ag) {                   // going on alone: the state holds the last rejected trial's gradient
-                                const dbl2 g_ = *prev_ag; gv = in ? g_.x : 0.0; gw = in ? g_.y : 0.0;
+                            if (rejected && have_prev) {                 // going on alone: the state holds the last rejected trial's gradient
+                                gv = in ? prev_g.x : 0.0; gw = in ? prev_g.y : 0.0;
                             }
+#ifdef NMPC_TL
+                            NMPC_TL_KEEP(uv + pv + gv + hv); NMPC_TL_EV(tl_it, 10);
+#endif
                             posted = false;
                             if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0);      // the request is over
                         }
@@ -1027,6 +1106,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         got = __builtin_amdgcn_readfirstlane(got);
         if (got < 0) { __builtin_amdgcn_s_sleep(2); continue; }
         const int w = got >> 28, k = got & 0xff;
+#ifdef NMPC_TL
+        const int tl_h = k == 0 ? (int)((lds_double *)lds + w * slice)[mp.par + 22] : -1;
+        NMPC_TL_EV(tl_h, 11);
+#endif
         const int seq = (got & 0x0fffffff) >> 8;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // the owner's slice: tables of its instance, multipliers, reference speeds, the request
@@ -1050,7 +1133,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
+#ifdef NMPC_TL
+        NMPC_TL_KEEP(zv + zw); NMPC_TL_EV(tl_h, 12);
+#endif
         eval_psi<PE, SH, false, CULL, WIN>(a, Lw, f2off, lane, te, zv, zw, c_w, cbar_w, y_w.x, y_w.y, vref_w, dyn_w, true, psi, pen, egv, egw, eav, eaw, near_w, &ws_h, OBSC ? &oc_h : nullptr, nullptr, &ek);
+#ifdef NMPC_TL
+        NMPC_TL_KEEP(psi + egv); NMPC_TL_EV(tl_h, 13);
+#endif
         if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (guard_load(Lw + mp.par + 19) != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
@@ -1069,6 +1158,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) ctl_store(ctl + CTL_DONE + (w * 3 + k) * TEAM_WAVES + wid, seq);
+#ifdef NMPC_TL
+        NMPC_TL_EV(tl_h, 14);
+#endif
     }
 }
 #undef pk_eps_nu

@@ -912,9 +912,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             ld4<H2_NS>(LY + 2 * H2_NS * (pj_), tt, y1_, y2_);                      \
                             const double al_ = rho_k * ga1;                                        \
                             ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                              \
-                            const double bc_ = row_bcast_lane<(J)>(al_);                           \
-                            ga2 = fma(-bc_, gy_, ga2);                                             \
-                            dv = fma2(-bc_, y1_, dv); dw = fma2(-bc_, y2_, dw);                    \
+                            fnma5_row_bcast<(J)>(ga2, dv.a, dv.b, dw.a, dw.b, al_, gy_, y1_.a, y1_.b, y2_.a, y2_.b, ga1); \
                         } while (0)
 #define NMPC2_GRAM_BWD(J)                                                                          \
                         do {                                                                       \
@@ -925,8 +923,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             const double be_ = rho_k * ga2;                                        \
                             const double ab_ = alv - be_;                                          \
                             ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                               \
-                            const double bc_ = row_bcast_lane<(J)>(ab_);                           \
-                            dv = fma2(bc_, s1_, dv); dw = fma2(bc_, s2_, dw);                      \
+                            fma4_row_bcast<(J)>(dv.a, dv.b, dw.a, dw.b, ab_, s1_.a, s1_.b, s2_.a, s2_.b, ga2); \
                         } while (0)
                         NMPC2_GRAM_FWD(0); NMPC2_GRAM_FWD(1); NMPC2_GRAM_FWD(2); NMPC2_GRAM_FWD(3); NMPC2_GRAM_FWD(4);
                         NMPC2_GRAM_FWD(5); NMPC2_GRAM_FWD(6); NMPC2_GRAM_FWD(7); NMPC2_GRAM_FWD(8); NMPC2_GRAM_FWD(9);

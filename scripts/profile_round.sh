@@ -6,7 +6,7 @@
 #      (traffic.json and scan_shares.json are copied into profiles/<tag>/ ON THE BOX before the bench lines: bench.py quotes them by source hash)
 #   3. rocprofv3 kernel trace + stats of the bench's timed steps, all four configurations             -> kernel_stats*.csv (must agree with kernel_ms)
 #   4. the bench lines: headline (the driver's command line), the other BASELINE configs, budget, RCCL at world size 1, the closed loop
-#   5. probes: seeds, small-batch latency, call latency, scheduler on / off, utilisation, scrub, cycles by section
+#   5. probes: seeds, small-batch latency, call latency, scheduler on / off, utilisation, scrub, cycles by section, timeline of a helped iteration
 # usage (through gpurun):  bash scripts/profile_round.sh r05
 set -u
 TAG=${1:-r05}
@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
 V=$PWD/mpc_trajectory_generator_amd/csrc/variants
 python -c "from mpc_trajectory_generator_amd import _lib; _lib.build_library(); _lib.build_variant(_lib.EXPERIMENTS)"      # (built before the call: they travel with the snapshot)
 XLIB=$V/libnmpc_experiments.so
-for f in ws:-DNMPC_WIN_STATS prof2:-DNMPC_PROF2 prof2e:-DNMPC_PROF2=2; do
+for f in ws:-DNMPC_WIN_STATS prof2:-DNMPC_PROF2 prof2e:-DNMPC_PROF2=2 tl:-DNMPC_TL; do
     [ -f $V/libnmpc_${f%%:*}.so ] || make -s -C mpc_trajectory_generator_amd/csrc -B OUT=variants/libnmpc_${f%%:*}.so EXTRA="${f#*:} -DNMPC_EXPERIMENTS"
 done
 SQ1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES"
@@ -53,4 +53,5 @@ python scripts/call_latency.py > "$OUT/call_latency.txt" 2>&1
 python scripts/scrub_probe.py shipped cfg1 cfg2 cfg3 cfg4 > "$OUT/scrub_probe.jsonl" 2>&1
 { NMPC_LIB_PATH=$V/libnmpc_prof2.so python scripts/sections.py cfg1 170 330; NMPC_TEAM_HELP=0 NMPC_LIB_PATH=$V/libnmpc_prof2.so python scripts/sections.py cfg1 170 330;
   NMPC_LIB_PATH=$V/libnmpc_prof2e.so python scripts/sections.py cfg1 170 330; } > "$OUT/sections.jsonl" 2> "$OUT/sections.log"
+{ NMPC_LIB_PATH=$V/libnmpc_tl.so python scripts/timeline.py 170; NMPC_LIB_PATH=$V/libnmpc_tl.so python scripts/timeline.py 330; } > "$OUT/timeline.jsonl" 2> "$OUT/timeline.log"
 python scripts/profile_summarise.py "$OUT" >> "$OUT/summarise.log" 2>&1
