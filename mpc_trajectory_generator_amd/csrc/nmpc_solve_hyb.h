@@ -224,6 +224,17 @@ __device__ __forceinline__ double lane_scalar(double v, int ln)
         fma2_row_bcast<(J)>(dv, dw, ab_, sp_.x, sp_.y, ga2);                                   \
     } while (0)
 
+// The state machine's wave-uniform flags are bits of ONE 32-bit scalar.  As `bool`s each is a 64-bit lane mask (two scalar registers,
+// tested through s_and_b64 with exec): seventeen of them across the loop body are a third of the scalar file, and what does not fit is
+// spilled to vector lanes, every reload a vector instruction.
+struct FlagBit {
+    unsigned &w;
+    const unsigned bit;
+    __device__ __forceinline__ operator bool() const { return (w & bit) != 0u; }
+    __device__ __forceinline__ FlagBit &operator=(bool v) { w = v ? (w | bit) : (w & ~bit); return *this; }
+    __device__ __forceinline__ FlagBit &operator=(const FlagBit &o) { return *this = (bool)o; }
+};
+
 template <class SH>
 __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArgs a)
 {
@@ -393,16 +404,17 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         double gv = 0, gw = 0, hv = 0, hw = 0, rv = 0, rw = 0, dv = 0, dw = 0;
         // (the query points of a pass -- X of this half -> evaluation points 0 and 1, Y -> point 2 -- and the trial point being consumed live
         // inside one pass: they are declared in the loop body, so that they do not occupy registers from one pass to the next)
-        bool need_grad = true;
+        unsigned fl = 0u;                         // the flags below (FlagBit)
+        FlagBit need_grad{fl, 1u << 0}; need_grad = true;
         double cost = 0, gamma = 0, tau = 1, rhs_ls = 0;
         pk_fbe_u = 0.0;
         pk_Lc = 0.0; pk_sigma = 0.0; pk_H0 = 1.0;
-        bool fbe_ok = false;                      // pk_fbe_u holds the FBE at the current iterate (an accepted trial's FBE is the next iteration's: same operands, same bits)
+        FlagBit fbe_ok{fl, 1u << 1};                      // pk_fbe_u holds the FBE at the current iterate (an accepted trial's FBE is the next iteration's: same operands, same bits)
         int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
-        bool lb_first = true;
+        FlagBit lb_first{fl, 1u << 2}; lb_first = true;
         // tentative L-BFGS update of the current iteration (committed when the Lipschitz test passes)
         int n_active = 0, n_head = 0;
-        bool n_first = true, n_take_old = false;
+        FlagBit n_first{fl, 1u << 3}, n_take_old{fl, 1u << 4}; n_first = true;
         double n_H0 = 1;
         unsigned num_iter = 0;
         const double c0 = a.c0 ? a.c0[inst] : 0.0;
@@ -415,10 +427,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         pk_dy_norm = 0.0; pk_f2_norm = 0.0; pk_dy_norm_plus = DBL_MAX; pk_f2_norm_plus = 0.0; pk_last_fpr = 0.0; pk_last_cost = 0.0; pk_norm_h = 0.0;
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
-        bool parked = false;
+        FlagBit parked{fl, 1u << 5};
         int park_cls = POOL_LONG;
         unsigned q_pass = 0;                      // n_pass at the last outer-iteration boundary (or at the start of this leg)
-        bool long_counted = false;                 // this instance is in the count of long instances alive (KArgs.pool_ctr[2 NPOOLS])
+        FlagBit long_counted{fl, 1u << 6};                 // this instance is in the count of long instances alive (KArgs.pool_ctr[2 NPOOLS])
         if (resumed) {                            // parked scalars
             const double *pks = a.park + (size_t)inst * PS + 6 * N;
             pen_c = pks[0];
@@ -431,9 +443,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
-        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
-        bool running = true, timed_out = false;
-        bool posted = false;                      // a request of the current iteration is open for the helpers
+        FlagBit f_start{fl, 1u << 7}, f_back{fl, 1u << 8}, f_trials{fl, 1u << 9}, f_end{fl, 1u << 10}, f_begin{fl, 1u << 11}, f_done{fl, 1u << 12}, f_fb{fl, 1u << 13};
+        FlagBit running{fl, 1u << 14}, timed_out{fl, 1u << 15};
+        f_start = true; running = true;
+        FlagBit posted{fl, 1u << 16};                      // a request of the current iteration is open for the helpers
 #ifdef NMPC_TL
         int tl_it = 0;                            // PANOC steps of this instance so far
 #endif

@@ -708,16 +708,17 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         D2 pv = d2s(0.0), pw = d2s(0.0);          // line-search trial point being consumed
         D2 xv = d2s(0.0), xw = d2s(0.0);          // query point X of THIS half (-> evaluation points 0 and 1)
         D2 yqv = d2s(0.0), yqw = d2s(0.0);        // query point Y (-> evaluation point 2)
-        bool need_grad = true;
+        unsigned fl = 0u;                         // the state machine's flags: bits of one scalar (FlagBit, nmpc_solve_hyb.h)
+        FlagBit need_grad{fl, 1u << 0}; need_grad = true;
         double cost = 0, gamma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0;
         double Lc = 0, sigma = 0, H0 = 1, c_lip = 0, gr = 0, norm_h = 0;
         double eps_nu = a.op.initial_tolerance, dy_norm = 0, f2_norm = 0, dy_norm_plus = DBL_MAX, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
         double fbe_u = 0;
-        bool fbe_ok = false;
+        FlagBit fbe_ok{fl, 1u << 1};
         int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
-        bool lb_first = true;
+        FlagBit lb_first{fl, 1u << 2}; lb_first = true;
         int n_active = 0, n_head = 0;
-        bool n_first = true, n_take_old = false;
+        FlagBit n_first{fl, 1u << 3}, n_take_old{fl, 1u << 4}; n_first = true;
         double n_H0 = 1;
         unsigned num_iter = 0;
         const double c0 = a.c0 ? a.c0[inst] : 0.0;
@@ -725,12 +726,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         double cbar_inv = 1.0 / fmax(pen_c, 1.0);
         int nu = 0, inner_status = 0, state = D_INIT, final_status = 0;
         unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
-        bool f_start = true, f_back = false, f_trials = false, f_end = false, f_begin = false, f_done = false, f_fb = false;
-        bool running = true, timed_out = false;
-        bool posted = false;
+        FlagBit f_start{fl, 1u << 7}, f_back{fl, 1u << 8}, f_trials{fl, 1u << 9}, f_end{fl, 1u << 10}, f_begin{fl, 1u << 11}, f_done{fl, 1u << 12}, f_fb{fl, 1u << 13};
+        FlagBit running{fl, 1u << 14}, timed_out{fl, 1u << 15}, posted{fl, 1u << 16};
+        f_start = true; running = true;
 
         unsigned q_pass = 0;                            // n_pass at the last outer-iteration boundary (or at the start of this leg)
-        bool parked = false, long_counted = false;      // (nmpc_solve_hyb.h: stepping aside at outer-iteration boundaries)
+        FlagBit parked{fl, 1u << 5}, long_counted{fl, 1u << 6};      // (nmpc_solve_hyb.h: stepping aside at outer-iteration boundaries)
         int park_cls = POOL_LONG;
         if (resumed) {
             const double *pks = pk + 6 * N;
