@@ -40,6 +40,10 @@ extern "C" {
 #endif
 
 #define NMPC_ABI_VERSION 3
+#define NMPC_MAX_HORIZON 40     /* longest N_hor served: the reference ships N_hor = 20 and 15 (configs/default.yaml:7,
+                                   configs/smooth_velocity.yaml:7); BASELINE's long-horizon case is 40.  nmpc_new returns
+                                   NMPC_ERR_BAD_PROBLEM beyond it (the one-point kernel that took 40 < N <= 64 until ABI 3's
+                                   first release -- another L-BFGS arithmetic, no obstacle certificate -- is gone) */
 
 typedef enum nmpc_error {
     NMPC_OK = 0,
@@ -54,7 +58,7 @@ typedef enum nmpc_error {
 /* What the reference bakes into the generated solver at build() time
  * (configs/default.yaml:6-13,18,34-40 ; src/mpc/mpc_generator.py:70-71,151-168). */
 typedef struct nmpc_problem {
-    int32_t N;        /* N_hor, 2..64                               */
+    int32_t N;        /* N_hor, 2..NMPC_MAX_HORIZON                 */
     int32_t nobs;     /* Nobs    : static circle slots, 0..64       */
     int32_t ndyn;     /* Ndynobs : dynamic ellipse slots, 0..3      */
     int32_t reserved;

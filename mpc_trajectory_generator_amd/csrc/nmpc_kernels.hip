@@ -38,6 +38,7 @@ constexpr int TEAM_REQ_DOUBLES = 3 * 24 * 2;
 constexpr int TEAM_AREA_DOUBLES = 3 * 24 * 2 + 8;     // + psi[3], envelope[3]
 constexpr int TEAM_CTL_INTS = 64;
 // instances waiting for a wave (nmpc_solve_hyb.h): long = an outer criterion is still open after the outer iteration just finished, cold = all hold: the next outer iteration is the last (and short)
+constexpr int EXCL_KEYS = 8192;      // (XCC, SE / SH, CU, SIMD) of a wave as one index: KArgs.excl
 constexpr int NPOOLS = 2;
 enum { POOL_LONG = 0, POOL_COLD = 1 };
 
@@ -101,6 +102,11 @@ struct KArgs {
     int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
     int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
     double cull_radius;        // eval_psi's CULL path: circles whose edge is farther than this from the start position are left out of the scan
+    // SIMD-exclusive long instances (nmpc_solve_hyb.h), NULL = off: one word per SIMD of the chip (the wave slot + 1 that holds it, 0 = free), then the number held
+    int *excl;
+    int excl_min;              // passes after which an instance asks for its SIMD
+    int excl_cap;              // SIMDs that may be held at a time
+    int excl_yield;            // 1: the other wave of a held SIMD parks its instance at the next outer-iteration boundary
     // eval kernel only
     const double *ev_c;
     const double *ev_y;
@@ -283,6 +289,11 @@ __device__ long long nmpc_tl[64 * 16];
 #else
 #define NMPC_TL_EV(it, ev) do { } while (0)
 #define NMPC_TL_KEEP(x) do { } while (0)
+#endif
+#ifdef NMPC_BBCOUNT
+// scripts/bbcount.py: one counter per basic block of ONE solve kernel.  The increments are not in this source: bbcount.py rewrites the
+// compiler's assembly (four instructions at the head of every block, registers the kernel does not use) and links the result against this array.
+__device__ __attribute__((used)) unsigned int nmpc_bbcnt[4096];
 #endif
 #ifdef NMPC_WIN_STATS
 __device__ unsigned long long nmpc_win_stats[4];       // evaluations that tried the window | of which fell back to the full scan | that tried the obstacle certificate | of which scanned
@@ -787,351 +798,6 @@ __global__ __launch_bounds__(64) void nmpc_eval_kernel(KArgs a)
     if (a.ev_F2) for (int k = t; k < a.n2; k += P) a.ev_F2[(size_t)b * a.n2 + k] = L[a.map.f2 + k];
 }
 
-// ---------------------------------------------------------------------------------------------
-// the solver: per-group state machine, one psi evaluation per pass
-// ---------------------------------------------------------------------------------------------
-enum : int { ST_IDLE = 0, ST_INIT0, ST_INIT1, ST_LIP, ST_FB0, ST_LS, ST_ALM };
-
-template <int P, class SH = ShapeAny>
-__global__ __launch_bounds__(64, 2) void nmpc_solve_kernel(KArgs a)
-{
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x, g = lane / P, t = lane % P;
-    const int gbase = g * P;
-    const LdsMap mp = the_map<SH, P>(a);
-    lds_double *L = (lds_double *)lds + g * mp.total;
-    const int N = a.pb.N, m = a.op.lbfgs_memory;
-    const bool in = t < N;
-    lds_double2 *LS = (lds_double2 *)(L + mp.S);
-    lds_double2 *LY = (lds_double2 *)(L + mp.Y);
-    lds_double *Lrho = L + mp.rho;
-
-    // ---- per-group state (every lane of a group holds the same control values) ----
-    int state = ST_IDLE, inst = -1;
-    bool done = false;                       // queue exhausted for this group
-    double vref = 0.0;
-    WinState ws = {0, 0.0, 0.0, 0.0};        // this lane's cross-track window (eval_psi, WIN)
-    DynStage dyn;
-    dyn.col = L + mp.dyn + t;
-    dyn.stride = P == 64 ? mp.dyn_stride : P;
-    // horizon vectors: (v, w) pair per lane
-    double uv = 0, uw = 0, gv = 0, gw = 0, sv_ = 0, sw_ = 0, hv = 0, hw = 0, rv = 0, rw = 0;   // u, grad, grad-step, half-step, gamma*fpr
-    double dv = 0, dw = 0, pv = 0, pw = 0, qv = 0, qw = 0;                                      // direction, u_plus, previous gradient
-    double gkv = 0, gkw = 0;                                                                    // gradient at the current iterate (ls_failure = 1)
-    bool timed_out = false;
-    double osv = 0, osw = 0, ogv = 0, ogw = 0;                                                  // L-BFGS old state / old gamma*fpr
-    double yv = 0, yw = 0, ypv = 0, ypw = 0;                                                    // multipliers y, y_plus
-    double zv = 0, zw = 0;                                                                      // query point of the next evaluation
-    bool need_grad = false;
-    // PANOC scalars
-    double cost = 0, Lc = 0, gamma = 0, sigma = 0, nr2 = 0, norm_r = 0, tau = 1, rhs_ls = 0, norm_h = 0, H0 = 1;
-    int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
-    bool lb_first = true;
-    unsigned num_iter = 0;
-    // ALM scalars
-    double pen_c = 1, eps_nu = 0, dy_norm = 0, f2_norm = 0, dy_norm_plus = 0, f2_norm_plus = 0, last_fpr = 0, last_cost = 0;
-    int nu = 0, inner_status = 0;
-    unsigned inner_total = 0, n_cost = 0, n_grad = 0, n_pass = 0;
-    long long t_start = 0;                   // 100 MHz clock at the fetch: per-instance solve_time_ms
-
-    for (;;) {
-        // ------------------------------------------------------------------ fetch work
-        if (state == ST_IDLE && !done) {
-            unsigned nxt = 0;
-            if (t == 0) nxt = atomicAdd(a.queue, 1u);
-            nxt = (unsigned)lane_get_i((int)nxt, gbase);
-            if (nxt >= (unsigned)a.B) {
-                done = true;
-            } else {
-                inst = a.order ? a.order[nxt] : (int)nxt;
-                t_start = (long long)__builtin_amdgcn_s_memrealtime();
-                n_pass = 0;
-                prepare_instance<P, SH>(a, L, a.p + (size_t)inst * a.n_p, t, vref, dyn);
-                ws = WinState{t < N - 1 ? t : N - 2, 0.0, 0.0, 0.0};       // this lane's cross-track window: nothing known yet
-                const double *u0 = a.u + (size_t)inst * a.n_u;
-                uv = in ? u0[2 * t] : 0.0;
-                uw = in ? u0[2 * t + 1] : 0.0;
-                yv = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + t] : 0.0;
-                yw = (a.y0 && in) ? a.y0[(size_t)inst * a.n1 + N + t] : 0.0;
-                ypv = yv; ypw = yw;
-                const double c0 = a.c0 ? a.c0[inst] : 0.0;
-                pen_c = c0 > 0.0 ? c0 : a.op.initial_penalty;
-                eps_nu = a.op.initial_tolerance;
-                dy_norm = f2_norm = f2_norm_plus = 0.0;
-                dy_norm_plus = DBL_MAX;
-                nu = 0; inner_total = 0; n_cost = 0; n_grad = 0; inner_status = 0; timed_out = false;
-                qv = qw = 0.0;                       // gradient_u_previous starts at zero for every solve
-                // outer iteration 0: y <- Pi_Y(y), start PANOC
-                yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);
-                lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
-                zv = uv; zw = uw; need_grad = true; state = ST_INIT0;
-            }
-        }
-        const bool live = state != ST_IDLE;
-        if (!__any(live)) break;
-
-        // ------------------------------------------------------------------ one evaluation of psi per group
-        double psi, pen, egv = 0, egw = 0, eav, eaw;
-        const bool wg = __any(live && need_grad);
-        eval_psi<P, SH, false, false, NMPC_WIN>(a, L, mp.f2, lane, t, zv, zw, pen_c, 1.0 / fmax(pen_c, 1.0), yv, yw, vref, dyn, wg, psi, pen, egv, egw, eav, eaw, ~0ull, &ws);
-        if (!live) continue;
-        n_pass++;
-
-        // ------------------------------------------------------------------ consume it
-        bool begin_step = false;      // (u, cost, g, grad-step, half-step) consistent: start the next PANOC step
-        bool end_iter = false;        // an iteration finished: count it, then begin_step
-        bool inner_done = false;
-        bool start_panoc = false;
-        bool finished = false;
-        int final_status = 0;
-
-        if (state == ST_INIT0) {
-            n_grad++;
-            cost = psi; gv = egv; gw = egw;
-            // local Lipschitz estimate: perturb u by h_i = max(1e-6 u_i, 1e-12)
-            const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
-            const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
-            norm_h = sqrt(group_sum<P>(in ? fma(h1, h1, h2 * h2) : 0.0, lane));
-            zv = in ? uv + h1 : 0.0;
-            zw = in ? uw + h2 : 0.0;
-            need_grad = true;
-            state = ST_INIT1;
-        } else if (state == ST_INIT1) {
-            n_grad++;
-            const double d1 = egv - gv, d2 = egw - gw;
-            Lc = sqrt(hdot<P>(d1, d2, d1, d2, lane)) / norm_h;
-            gamma = GAMMA_L_COEFF / fmax(Lc, MIN_LIPSCHITZ_CONSTANT);
-            sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-            sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
-            hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
-            hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
-            begin_step = true;
-        } else if (state == ST_LIP) {
-            n_cost++;
-            const double cost_uh = psi;
-            const double rhs = cost + LIPSCHITZ_UPDATE_EPSILON * fabs(cost) - hdot<P>(gv, gw, rv, rw, lane)
-                             + (GAMMA_L_COEFF / (2.0 * gamma)) * nr2;
-            if (lip_it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && Lc < MAX_LIPSCHITZ_CONSTANT && cost_uh > rhs) {
-                lb_active = 0; lb_first = true;                   // L-BFGS buffer invalidated
-                Lc *= 2.0;
-                gamma /= 2.0;
-                sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
-                hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
-                hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
-                rv = uv - hv; rw = uw - hw;
-                nr2 = hdot<P>(rv, rw, rv, rw, lane);
-                norm_r = sqrt(nr2);
-                lip_it++;
-                zv = hv; zw = hw; need_grad = false;              // stay in ST_LIP
-            } else {
-                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-                // ---- L-BFGS update with (s, y) = (u - u_old, r - r_old) ----
-                if (lb_first) {
-                    lb_first = false;
-                    osv = uv; osw = uw; ogv = rv; ogw = rw;
-                } else {
-                    const double s1 = uv - osv, s2 = uw - osw, y1 = rv - ogv, y2 = rw - ogw;
-                    const double ys = hdot<P>(s1, s2, y1, y2, lane), ss = hdot<P>(s1, s2, s1, s2, lane);
-                    bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
-                    if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
-                    if (ok) {
-                        osv = uv; osw = uw; ogv = rv; ogw = rw;
-                        lb_head = lb_head == 0 ? m - 1 : lb_head - 1;
-                        if (in) { LS[lb_head * N + t] = dbl2{s1, s2}; LY[lb_head * N + t] = dbl2{y1, y2}; }
-                        if (t == 0) Lrho[lb_head] = 1.0 / ys;
-                        H0 = ys / hdot<P>(y1, y2, y1, y2, lane);
-                        if (lb_active < m) lb_active++;
-                        NMPC_WAVE_SYNC();
-                    }
-                }
-                if (iteration == 0) {
-                    // first iteration: plain forward-backward step, no line search
-                    uv = hv; uw = hw;
-                    zv = uv; zw = uw; need_grad = true;
-                    state = ST_FB0;
-                } else {
-                    // ---- direction d = H r by the two-loop recursion ----
-                    dv = rv; dw = rw;
-                    double alpha[MAXMEM];
-#pragma unroll
-                    for (int k = 0; k < MAXMEM; ++k) {
-                        alpha[k] = 0.0;
-                        if (k < lb_active) {
-                            int slot = lb_head + k; if (slot >= m) slot -= m;
-                            const dbl2 s = in ? LS[slot * N + t] : dbl2{0.0, 0.0};
-                            const dbl2 y = in ? LY[slot * N + t] : dbl2{0.0, 0.0};
-                            const double al = Lrho[slot] * hdot<P>(s.x, s.y, dv, dw, lane);
-                            alpha[k] = al;
-                            dv = fma(-al, y.x, dv); dw = fma(-al, y.y, dw);
-                        }
-                    }
-                    if (lb_active > 0) { dv = H0 * dv; dw = H0 * dw; }
-#pragma unroll
-                    for (int k = MAXMEM - 1; k >= 0; --k) {
-                        if (k < lb_active) {
-                            int slot = lb_head + k; if (slot >= m) slot -= m;
-                            const dbl2 s = in ? LS[slot * N + t] : dbl2{0.0, 0.0};
-                            const dbl2 y = in ? LY[slot * N + t] : dbl2{0.0, 0.0};
-                            const double be = Lrho[slot] * hdot<P>(y.x, y.y, dv, dw, lane);
-                            const double ab = alpha[k] - be;
-                            dv = fma(ab, s.x, dv); dw = fma(ab, s.y, dw);
-                        }
-                    }
-                    // ---- line search set-up: rhs = FBE(u) - sigma ||r||^2 ----
-                    const double e1 = sv_ - hv, e2 = sw_ - hw;
-                    const double dist2 = group_sum<P>(fma(e1, e1, e2 * e2), lane);
-                    const double gg = hdot<P>(gv, gw, gv, gw, lane);
-                    const double fbe = cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
-                    rhs_ls = fbe - sigma * nr2;
-                    tau = 1.0; ls_n = 0;
-                    const double omt = 1.0 - tau;
-                    pv = fma(-tau, dv, fma(-omt, rv, uv));
-                    pw = fma(-tau, dw, fma(-omt, rw, uw));
-                    qv = gv; qw = gw;                              // cache_previous_gradient
-                    gkv = gv; gkw = gw;
-                    zv = pv; zw = pw; need_grad = true;
-                    state = ST_LS;
-                }
-            }
-        } else if (state == ST_FB0) {
-            n_grad++;
-            cost = psi; gv = egv; gw = egw;
-            sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
-            hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
-            hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
-            end_iter = true;
-        } else if (state == ST_LS) {
-            n_grad++;
-            cost = psi; gv = egv; gw = egw;
-            sv_ = fma(-gamma, gv, pv); sw_ = fma(-gamma, gw, pw);
-            hv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
-            hw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
-            const double e1 = sv_ - hv, e2 = sw_ - hw;
-            const double dist2 = group_sum<P>(fma(e1, e1, e2 * e2), lane);
-            const double gg = hdot<P>(gv, gw, gv, gw, lane);
-            const double lhs = cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
-            if (lhs > rhs_ls && ls_n < MAX_LINESEARCH_ITERATIONS) {
-                tau /= 2.0; ls_n++;
-                const double omt = 1.0 - tau;
-                pv = fma(-tau, dv, fma(-omt, rv, uv));
-                pw = fma(-tau, dw, fma(-omt, rw, uw));
-                qv = gv; qw = gw;
-                zv = pv; zw = pw; need_grad = true;                // stay in ST_LS
-            } else if (lhs > rhs_ls && a.op.ls_failure == 1) {
-                // every trial failed, tau = 0: forward-backward step from the current iterate
-                tau = 0.0;
-                gv = gkv; gw = gkw;
-                sv_ = fma(-gamma, gv, uv); sw_ = fma(-gamma, gw, uw);
-                uv = in ? clampd(sv_, a.pb.vmin, a.pb.vmax) : sv_;
-                uw = in ? clampd(sw_, -a.pb.wmax, a.pb.wmax) : sw_;
-                zv = uv; zw = uw; need_grad = true;
-                state = ST_FB0;
-            } else {
-                uv = pv; uw = pw;
-                end_iter = true;
-            }
-        } else if (state == ST_ALM) {
-            n_cost++;
-            // y+ = y + c (F1 - Pi_C(F1 + y / max(c,1))), ||y+ - y||, ||F2||
-            const double cbar_inv = 1.0 / fmax(pen_c, 1.0);
-            const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
-            ypv = in ? fma(pen_c, eav - clampd(tv, a.pb.amin, a.pb.amax), yv) : 0.0;
-            ypw = in ? fma(pen_c, eaw - clampd(tw, -a.pb.awmax, a.pb.awmax), yw) : 0.0;
-            const double d1 = ypv - yv, d2 = ypw - yw;
-            dy_norm_plus = sqrt(group_sum<P>(in ? fma(d1, d1, d2 * d2) : 0.0, lane));
-            f2_norm_plus = sqrt(pen);
-            const double SMALL = DBL_EPSILON;
-            const bool crit1 = nu > 0 && dy_norm_plus <= pen_c * a.op.delta_tolerance + SMALL;
-            const bool crit2 = a.n2 == 0 || f2_norm_plus <= a.op.delta_tolerance + SMALL;
-            const bool crit3 = eps_nu <= a.op.tolerance + SMALL;
-            if (crit1 && crit2 && crit3) {
-                finished = true; final_status = a.op.inner_status == 1 ? NMPC_CONVERGED : inner_status;
-            } else {
-                const bool stall = nu == 0 || (dy_norm_plus <= a.op.sufficient_decrease * dy_norm + SMALL &&
-                                               f2_norm_plus <= a.op.sufficient_decrease * f2_norm + SMALL);
-                if (!stall) pen_c *= a.op.penalty_update;
-                eps_nu = fmax(a.op.tolerance_update * eps_nu, a.op.tolerance);
-                yv = ypv; yw = ypw;
-                dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
-                nu++;
-                if (nu == a.op.max_outer) { finished = true; final_status = NMPC_NOT_CONVERGED_ITERATIONS; }
-                else if (timed_out) { finished = true; final_status = NMPC_NOT_CONVERGED_OUT_OF_TIME; nu--; }   // (the report below adds the one back)
-                else start_panoc = true;
-            }
-        }
-
-        if (end_iter) {
-            iteration++;
-            // OpEn: while step() && num_iter < max_iter { num_iter++ }
-            if (!(num_iter < (unsigned)a.op.max_inner)) inner_done = true;
-            else {
-                num_iter++;
-                if (a.op.max_total_inner > 0 && inner_total + num_iter >= (unsigned)a.op.max_total_inner) { timed_out = true; inner_done = true; }
-                else begin_step = true;
-            }
-        }
-        if (begin_step) {
-            rv = uv - hv; rw = uw - hw;
-            nr2 = hdot<P>(rv, rw, rv, rw, lane);
-            norm_r = sqrt(nr2);
-            bool exit_now = false;
-            if (norm_r < a.op.tolerance) {                         // fpr test, then the AKKT test (opts.akkt_gradient)
-                if (a.op.akkt_gradient == 2) exit_now = true;
-                else {
-                    const bool top = a.op.akkt_gradient == 1;      // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
-                    const double b1 = top ? (iteration >= 1 ? 0.0 : gv) : gv - qv, b2 = top ? (iteration >= 1 ? 0.0 : gw) : gw - qw;
-                    const double a1 = rv / gamma + b1, a2 = rw / gamma + b2;
-                    exit_now = sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < eps_nu;
-                }
-            }
-            if (exit_now) inner_done = true;
-            else { lip_it = 0; zv = hv; zw = hw; need_grad = false; state = ST_LIP; }
-        }
-        if (inner_done) {
-            inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
-                                     : (num_iter < (unsigned)a.op.max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
-            inner_total += num_iter;
-            last_fpr = norm_r; last_cost = cost;
-            uv = hv; uw = hw;                                      // PANOC returns the feasible half step
-            const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
-            if (group_sum<P>((in && !fin) ? 1.0 : 0.0, lane) > 0.0) {
-                finished = true; final_status = NMPC_NOT_CONVERGED_NOT_FINITE;
-            } else {
-                zv = uv; zw = uw; need_grad = false; state = ST_ALM;
-            }
-        }
-        if (start_panoc) {
-            yv = clampd(yv, -1e12, 1e12); yw = clampd(yw, -1e12, 1e12);
-            lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
-            zv = uv; zw = uw; need_grad = true; state = ST_INIT0;
-        }
-        if (finished) {
-            if (in) {
-                double *uo = a.u + (size_t)inst * a.n_u;
-                uo[2 * t] = uv; uo[2 * t + 1] = uw;
-                if (a.y_out) { a.y_out[(size_t)inst * a.n1 + t] = ypv; a.y_out[(size_t)inst * a.n1 + N + t] = ypw; }
-            }
-            if (t == 0 && a.st) {
-                nmpc_status s;
-                s.exit_status = final_status;
-                s.num_outer_iterations = (uint32_t)(final_status == NMPC_NOT_CONVERGED_NOT_FINITE ? nu + 1 : (nu < a.op.max_outer ? nu + 1 : nu));
-                s.num_inner_iterations = inner_total;
-                s.num_cost_evals = n_cost;
-                s.num_grad_evals = n_grad;
-                s.reserved = n_pass;                 // evaluation passes executed (one query point each)
-                s.last_problem_norm_fpr = last_fpr;
-                s.delta_y_norm_over_c = dy_norm_plus / pen_c;
-                s.f2_norm = f2_norm_plus;
-                s.penalty = pen_c;
-                s.cost = last_cost;
-                s.solve_time_ms = (double)((long long)__builtin_amdgcn_s_memrealtime() - t_start) * 1e-5;
-                a.st[inst] = s;
-            }
-            state = ST_IDLE;
-        }
-    }
-}
-
 }  // namespace nmpc
 
 namespace nmpc {
@@ -1196,6 +862,18 @@ __global__ void nmpc_classify_kernel(KArgs a, unsigned char *cls)
     cls[b] = (unsigned char)((graze ? 4 : 0) + (early ? 4 : 0) + (hard ? 1 : 0) + (bend > SCHED_BEND ? 1 : 0) + (gap ? 1 : 0) + (goal ? 1 : 0));
 }
 
+// The same levels from what a receding-horizon loop already knows: the evaluation passes each instance's solve took one step earlier
+// (nmpc_status.reserved).  Consecutive solves of one robot are alike -- the previous count is a far better predictor of the next than anything the
+// inputs show -- so the closed loop hands out its instances longest-last-time first (nmpc_loop_step); level = position of the count's top bit.
+__global__ void nmpc_classify_prev_kernel(int B, const nmpc_status *prev, unsigned char *cls)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned n = prev[b].reserved;
+    const int lvl = n < 32u ? 0 : (31 - __clz((int)n)) - 4;      // 32..63 passes -> 1, 64..127 -> 2, ...
+    cls[b] = (unsigned char)(lvl > SCHED_LEVELS - 1 ? SCHED_LEVELS - 1 : lvl);
+}
+
 // stable partition of 0..B-1 by level (highest first); one block, deterministic
 __global__ void nmpc_order_kernel(int B, const unsigned char *cls, int *order)
 {
@@ -1249,7 +927,7 @@ struct nmpc_handle {
     int max_batch;
     bool alive;
     LdsMap map;
-    int P;                 // lanes per query point (20: three points per wave, 32: two, 64: one; 40: three points, two stages per lane)
+    int P;                 // 20: three query points per wave, one stage per lane (N_hor <= 20); 40: three points, two stages per lane (20 < N_hor <= 40)
     bool shape_default;    // (N, Nobs, Ndynobs) == ShapeDefault: the shape-specialised kernel runs
     bool shape_nobs50;     // ... == ShapeNobs50
     bool shape_n40;        // ... == ShapeN40
@@ -1266,8 +944,12 @@ struct nmpc_handle {
     double *d_park;            // parked solver states, allocated on first use
     int *d_pool;
     unsigned int *d_pool_ctr;
+    int *d_excl;               // SIMD-exclusive long instances: KArgs.excl
+    int excl_min, excl_cap, excl_yield;
+    bool loop_order_prev;      // nmpc_loop_step: launch order from the previous step's pass counts (experiments: NMPC_LOOP_ORDER_PREV=0 switches it off)
     int *d_order;              // launch order (hard-looking instances first)
     bool use_order;
+    const nmpc_status *order_hint;   // set by nmpc_loop_step for the duration of its solve: the previous step's statuses (launch order by their pass counts)
     unsigned char *d_cls;
     // staging buffers of the host path
     double *d_p, *d_u, *d_y0, *d_c0, *d_yout, *d_psi, *d_grad, *d_F1, *d_F2;
@@ -1338,7 +1020,7 @@ static LdsMap make_map(const nmpc_problem &pb, int P) { return nmpc::lds_layout(
 int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int max_batch, nmpc_handle **out)
 {
     if (!pb || !out || max_batch < 1) return NMPC_ERR_BAD_ARG;
-    if (pb->N < 2 || pb->N > 64 || pb->nobs < 0 || pb->nobs > 64 || pb->ndyn < 0 || pb->ndyn > nmpc::NDYN_MAX ||
+    if (pb->N < 2 || pb->N > NMPC_MAX_HORIZON || pb->nobs < 0 || pb->nobs > 64 || pb->ndyn < 0 || pb->ndyn > nmpc::NDYN_MAX ||
         !(pb->ts > 0.0))
         return NMPC_ERR_BAD_PROBLEM;
     nmpc_opts op;
@@ -1352,7 +1034,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         return NMPC_ERR_NO_DEVICE;
     nmpc_handle *h = new nmpc_handle();
     h->pb = *pb; h->op = op; h->device = device_id; h->max_batch = max_batch; h->alive = true; h->last_ms = 0.0;
-    h->P = pb->N <= 20 ? 20 : (pb->N <= 40 ? 40 : 64);      // (the two-point kernel that served 20 < N <= 32 is retired: the two-stage kernel takes those horizons)
+    h->P = pb->N <= 20 ? 20 : 40;      // one stage per lane (nmpc_solve_hyb.h) / two stages per lane (nmpc_solve_hyb2.h); longer horizons are not served
     h->shape_default = pb->N == nmpc::ShapeDefault::N && pb->nobs == nmpc::ShapeDefault::NOBS &&
                        pb->ndyn == nmpc::ShapeDefault::NDYN;
     h->shape_nobs50 = pb->N == nmpc::ShapeNobs50::N && pb->nobs == nmpc::ShapeNobs50::NOBS &&
@@ -1365,8 +1047,10 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
 #endif
     h->map = make_map(*pb, h->P == 40 ? 64 : h->P);      // (P = 40: the kernels compute their own map, nmpc_solve_hyb2.h)
     h->d_queue = nullptr;
-    h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
+    h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr; h->d_excl = nullptr;
     h->park_min = 500; h->park_depth = 8;
+    h->excl_min = 0; h->excl_cap = 256; h->excl_yield = 0;
+    h->loop_order_prev = true;
     // long instances time-share beyond this fraction of the resident waves: the favoured half of them for the one-stage kernel (two waves per SIMD),
     // 0.8 for the two-stage kernel (one wave per SIMD); measured flat between 0.4 and 0.7 / 0.5 and 1.0 (profiles/r04/sched_sweep*.txt)
     h->sched_mode = 1; h->sched_theta = h->P == 20 ? 0.5 : 0.8;
@@ -1377,9 +1061,14 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     // with a stage beyond it scans every circle); NMPC_CULL_RADIUS overrides it (tests use 0.5 m: the fall-back runs all the time)
     h->cull_radius = 1.1 * pb->N * pb->ts * fmax(fabs(pb->vmin), fabs(pb->vmax));
     h->use_order = true;
+    h->order_hint = nullptr;
 #ifdef NMPC_EXPERIMENTS      // knobs of the experiments build: tests use them to check that every setting gives the same bits, scripts to measure
     if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // 0 switches the slot migration off
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
+    if (const char *env = getenv("NMPC_LOOP_ORDER_PREV")) h->loop_order_prev = atoi(env) != 0;
+    if (const char *env = getenv("NMPC_EXCL_MIN")) h->excl_min = atoi(env);       // 0 = no SIMD is ever held
+    if (const char *env = getenv("NMPC_EXCL_CAP")) h->excl_cap = atoi(env);
+    if (const char *env = getenv("NMPC_EXCL_YIELD")) h->excl_yield = atoi(env);
     if (const char *env = getenv("NMPC_SCHED")) h->sched_mode = atoi(env);
     if (const char *env = getenv("NMPC_SCHED_THETA")) { const double v = atof(env); if (v > 0.0) h->sched_theta = v; }
     if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
@@ -1420,7 +1109,7 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
-    } else if (h->P == 40) {
+    } else {
         // two stages per lane: one wave per SIMD (512 registers), the four waves of a CU are one team
         const size_t wg_bytes = nmpc::TEAM_WAVES * (size_t)nmpc::lds_layout2(pb->N, pb->nobs, pb->ndyn).total * sizeof(double) +
                                 nmpc::TEAM_CTL_INTS * sizeof(int);
@@ -1431,14 +1120,11 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_solve_hyb2_kernel<nmpc::ShapeAny>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nmpc::nmpc_eval2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { nmpc_free(h); return NMPC_ERR_HIP; }
-    } else {
-        per_cu = (int)((160 * 1024) / ((size_t)h->map.total * sizeof(double)));
-        if (per_cu > 8) per_cu = 8;
     }
 #ifdef NMPC_EXPERIMENTS
     if (const char *env = getenv("NMPC_WAVES_PER_CU")) {
         const int v = atoi(env);
-        if (v >= 1 && v <= per_cu && ((h->P != 20 && h->P != 40) || v % nmpc::TEAM_WAVES == 0)) per_cu = v;
+        if (v >= 1 && v <= per_cu && v % nmpc::TEAM_WAVES == 0) per_cu = v;
     }
 #endif
     if (per_cu < 1) per_cu = 1;
@@ -1452,7 +1138,7 @@ void nmpc_free(nmpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_queue); (void)hipFree(h->d_order); (void)hipFree(h->d_cls);
-    (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr);
+    (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr); (void)hipFree(h->d_excl);
     for (int k = 0; k < 2; ++k) { if (h->h_pin[k]) (void)hipHostFree(h->h_pin[k]); if (h->pin_ev[k]) (void)hipEventDestroy(h->pin_ev[k]); }
     (void)hipFree(h->d_small); if (h->h_small) (void)hipHostFree(h->h_small);
     for (int k = 0; k < 2; ++k) if (h->small_ev[k]) (void)hipEventDestroy(h->small_ev[k]);
@@ -1470,8 +1156,7 @@ const char *nmpc_kernel_name(const nmpc_handle *h)
     if (h->P == 20)
         return h->shape_default ? "nmpc_solve_hyb_kernel<ShapeDefault>"
                                 : (h->shape_nobs50 ? "nmpc_solve_hyb_kernel<ShapeNobs50>" : "nmpc_solve_hyb_kernel<ShapeAny>");
-    if (h->P == 40) return h->shape_n40 ? "nmpc_solve_hyb2_kernel<ShapeN40>" : "nmpc_solve_hyb2_kernel<ShapeAny>";
-    return "nmpc_solve_kernel<64>";
+    return h->shape_n40 ? "nmpc_solve_hyb2_kernel<ShapeN40>" : "nmpc_solve_hyb2_kernel<ShapeAny>";
 }
 
 static void fill_args(const nmpc_handle *h, KArgs &a, int B)
@@ -1499,12 +1184,12 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
     fill_args(h, a, B);
     a.p = d_p; a.u = d_u; a.y0 = d_y0; a.c0 = d_c0; a.y_out = d_y_out; a.st = d_status;
     HIP_TRY(h, hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), s));
-    // one instance per wave: N_hor <= 20 evaluates three query points per pass (hybrid / tri layouts),
-    // 20 < N_hor <= 40 three with two stages per lane, longer horizons one, with the whole wave as one group
+    // one instance per wave, three query points per pass: N_hor <= 20 with one stage per lane (hybrid / tri layouts), 20 < N_hor <= 40 with two
     const int grid = B < h->grid_cap ? B : h->grid_cap;          // waves that take instances
     if (B > grid) {        // more instances than resident waves: hand the hard-looking ones out first
         if (h->use_order) {
-            hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
+            if (h->order_hint) hipLaunchKernelGGL(nmpc::nmpc_classify_prev_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, h->order_hint, h->d_cls);
+            else hipLaunchKernelGGL(nmpc::nmpc_classify_kernel, dim3((B + 255) / 256), dim3(256), 0, s, a, h->d_cls);
             hipLaunchKernelGGL(nmpc::nmpc_order_kernel, dim3(1), dim3(1024), 0, s, B, h->d_cls, h->d_order);
             a.order = h->d_order;
         }
@@ -1523,10 +1208,14 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
             a.park_min = h->P == 20 ? h->park_min : 0; a.park_depth = h->park_depth;      // (the slot migration is the one-stage kernel's: two waves per SIMD)
             a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr; a.pool_cap = (int)cap;
             a.sched_mode = h->sched_mode;
+            if (h->P == 20 && h->excl_min > 0) {
+                if (!h->d_excl) HIP_TRY(h, hipMalloc((void **)&h->d_excl, (nmpc::EXCL_KEYS + 1) * sizeof(int)));
+                HIP_TRY(h, hipMemsetAsync(h->d_excl, 0, (nmpc::EXCL_KEYS + 1) * sizeof(int), s));
+                a.excl = h->d_excl; a.excl_min = h->excl_min; a.excl_cap = h->excl_cap; a.excl_yield = h->excl_yield;
+            }
         }
     }
-    const size_t lds = (size_t)h->map.total * sizeof(double);
-    if (h->P == 20 || h->P == 40) {
+    {
         // teams of four waves.  With fewer instances than workgroups fit on the chip every instance gets a workgroup of its
         // own (one wave solves, three help from the first iteration on: the small-batch / latency mode); otherwise as many
         // waves per workgroup take instances as it needs for all of them to start at once, up to all four.
@@ -1550,7 +1239,6 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
         else if (h->shape_nobs50) hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeNobs50>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
         else hipLaunchKernelGGL(nmpc::nmpc_solve_hyb_kernel<nmpc::ShapeAny>, dim3(wgs), dim3(64 * nmpc::TEAM_WAVES), tlds, s, a);
     }
-    else hipLaunchKernelGGL(nmpc::nmpc_solve_kernel<64>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
 }
@@ -1575,11 +1263,10 @@ int nmpc_eval_batch_device(nmpc_handle *h, int B, const double *d_p, const doubl
         HIP_TRY(h, hipGetLastError());
         return NMPC_OK;
     }
-    const int K = 64 / h->P;
+    const int K = 3;                       // instances per wave: the tri layout
     const int grid = (B + K - 1) / K;
     const size_t lds = (size_t)h->map.total * sizeof(double) * K;
-    if (h->P == 20) hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<20>, dim3(grid), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<64>, dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(nmpc::nmpc_eval_kernel<20>, dim3(grid), dim3(64), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return NMPC_OK;
 }
@@ -1869,7 +1556,11 @@ int nmpc_loop_step(nmpc_loop *l, void *stream)
     hipLaunchKernelGGL(nmpc::nmpc_loop_assemble_kernel, dim3(a.B), dim3(64), 0, s, a);
     HIP_TRY(h, hipGetLastError());
     // warm start: previous controls and multipliers, penalty back to its initial value (the server's behaviour)
+    // launch order: from the second step on, by the pass counts of the step before (read by the classification kernel ahead of the solve, which
+    // then overwrites them); the first step has only the inputs to go by
+    h->order_hint = (l->steps > 0 && h->loop_order_prev) ? l->d_st : nullptr;
     const int rc = nmpc_solve_batch_device(h, a.B, l->d_P, l->d_U, l->d_Y, nullptr, l->d_Y, l->d_st, stream);
+    h->order_hint = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(nmpc::nmpc_loop_advance_kernel, dim3((a.B + 255) / 256), dim3(256), 0, s, a);
     HIP_TRY(h, hipGetLastError());
@@ -1968,6 +1659,15 @@ int nmpc_test_divsqrt_host(nmpc_handle *h, int n, const double *a, const double 
 #ifdef NMPC_TL
 // experiments only (scripts/timeline.py)
 int nmpc_debug_timeline(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(nmpc::nmpc_tl), 64 * 16 * sizeof(long long)) == hipSuccess ? NMPC_OK : NMPC_ERR_HIP; }
+#endif
+#ifdef NMPC_BBCOUNT
+// experiments only (scripts/bbcount.py): executions of every basic block of the instrumented kernel since the last reset
+int nmpc_debug_bbcount(unsigned int *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nmpc::nmpc_bbcnt), 4096 * sizeof(unsigned int));
+    if (e == hipSuccess && reset) { static const unsigned int z[4096] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(nmpc::nmpc_bbcnt), z, sizeof z); }
+    return e == hipSuccess ? NMPC_OK : NMPC_ERR_HIP;
+}
 #endif
 #ifdef NMPC_WIN_STATS
 // experiments only (scripts/win_stats.py): windowed cross-track searches and how many of them fell back to the full scan

@@ -40,15 +40,15 @@ __device__ __forceinline__ void pair_sum(double a, double b, int lane, double &s
     sum_b = s2;
 }
 
-// forward-backward envelope at the point whose cost / gradient / gradient step / half step are given
+// forward-backward envelope at the point whose cost / gradient / gradient step / half step are given; hig = 0.5 / gamma (formed when gamma changes)
 template <int P>
-__device__ __forceinline__ double fbe_value(double cost, double gamma, double sv, double sw, double hv, double hw,
+__device__ __forceinline__ double fbe_value(double cost, double gamma, double hig, double sv, double sw, double hv, double hw,
                                             double gv, double gw, int lane)
 {
     const double e1 = sv - hv, e2 = sw - hw;
     double dist2, gg;
     pair_sum(fma(e1, e1, e2 * e2), fma(gv, gv, gw * gw), lane, dist2, gg);
-    return cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
+    return cost - (0.5 * gamma) * gg + dist2 * hig;
 }
 
 

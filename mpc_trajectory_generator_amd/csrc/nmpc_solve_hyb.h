@@ -49,25 +49,17 @@ namespace nmpc {
 
 typedef __attribute__((address_space(3))) int lds_int;
 // control block of a workgroup, after the four slices
-enum { CTL_OWNERS = 0, CTL_HELPERS = 1, CTL_CLAIM = 4, CTL_DONE = 8 };     // done: [owner][task][helper]
+enum { CTL_OWNERS = 0, CTL_HELPERS = 1, CTL_CLAIM = 4, CTL_DONE = 8, CTL_INST = 56 };     // done: [owner][task][helper]; inst: [owner]
 __device__ __forceinline__ int ctl_load(lds_int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ctl_store(lds_int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int ctl_add(lds_int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// The instance id in an owner's slice (Lpar[19]) guards what a helper lane has learnt about the owner's tables (cross-track window, obstacle
-// certificate): the owner takes the id away (-1) BEFORE it rewrites the tables and puts the new one back AFTER, the helper reads the id before
-// and after its evaluation.  A sequence lock -- so the accesses are atomic (the compiler may neither merge the helper's two reads nor drop
-// the owner's first store) and fenced at workgroup scope (the id is released after / acquired before the table accesses it guards).
-typedef __attribute__((address_space(3))) long long lds_i64;
-__device__ __forceinline__ void guard_store(lds_double *p, double v)
-{
-    __hip_atomic_store((lds_i64 *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ double guard_load(const lds_double *p)
-{
-    return __longlong_as_double(__hip_atomic_load((lds_i64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-
+// The instance id of an owner (ctl[CTL_INST + wave]; -1: none) guards what a helper lane has learnt about the owner's tables (cross-track window,
+// obstacle certificate): the owner takes the id away BEFORE it rewrites the tables -- for its next instance, or with the result areas once it
+// has turned helper itself -- and puts the new one back AFTER; the helper reads the id before and after its evaluation.  A sequence lock: the
+// accesses are atomic (ctl_load / ctl_store: the compiler may neither merge the helper's two reads nor drop the owner's first store) and fenced
+// at workgroup scope (the id is released after / acquired before the table accesses it guards).  It lives in the control block, not in the
+// slice: a slice is overwritten from offset 0 by the result areas of its wave's helper phase.
 // a query point's scalar (psi): every lane of the point's row holds it; rows 0..2 are points 0..2
 __device__ __forceinline__ double point_scalar(double v, int k)
 {
@@ -91,7 +83,7 @@ __device__ __forceinline__ double point_scalar(double v, int k)
         hw = ina ? clampd(s2_, -wmax, wmax) : s2_;                             \
     } while (0)
 // FBE at the cached point; the gradient step x - gamma g is recomputed (bitwise the same value)
-#define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
+#define NMPC_FBE(xv, xw) fbe_value<P>(cost, gamma, pk_hig, fma(-gamma, gv, (xv)), fma(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
 
 // parked-instance pool: one lane calls these.  Entries are published with release semantics at agent scope and
 // read with acquire semantics (other XCDs' L2s are not coherent with ours: plain loads could see stale lines)
@@ -235,6 +227,25 @@ struct FlagBit {
     __device__ __forceinline__ FlagBit &operator=(const FlagBit &o) { return *this = (bool)o; }
 };
 
+// SIMD-exclusive long instances: this wave's word of KArgs.excl (nullptr: off) and the counter of held SIMDs, read afresh from the
+// kernel-argument segment (volatile: the loads stay where they are written)
+struct ExclRef { int *word, *count; int min_passes, cap, yield; };
+__device__ __forceinline__ ExclRef excl_ref()
+{
+    typedef __attribute__((address_space(4))) const volatile char ka_bytes;
+    ka_bytes *ka = (ka_bytes *)__builtin_amdgcn_kernarg_segment_ptr();
+    ExclRef r;
+    int *base = *(int *__attribute__((address_space(4))) const volatile *)(ka + offsetof(KArgs, excl));
+    r.min_passes = *(__attribute__((address_space(4))) const volatile int *)(ka + offsetof(KArgs, excl_min));
+    r.cap = *(__attribute__((address_space(4))) const volatile int *)(ka + offsetof(KArgs, excl_cap));
+    r.yield = *(__attribute__((address_space(4))) const volatile int *)(ka + offsetof(KArgs, excl_yield));
+    const unsigned hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+    const int key = (int)(((xcc & 7u) << 9) | (((hw >> 12) & 7u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u));      // XCC | SE, SH | CU | SIMD
+    r.word = base ? base + key : nullptr;
+    r.count = base ? base + EXCL_KEYS : nullptr;
+    return r;
+}
+
 template <class SH>
 __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArgs a)
 {
@@ -312,6 +323,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #define pk_sigma Lpar[10]
 #define pk_c_lip Lpar[11]
 #define pk_fbe_u Lpar[20]       /* FBE at the current iterate */
+#define pk_hig Lpar[19]         /* 0.5 / gamma, refreshed when gamma changes (the envelope's last term is dist2 * pk_hig); helpers read it with the request */
 #define pk_gr Lpar[12]          /* <grad psi, r> of the current iterate: summed together with ||r||^2, used by the Lipschitz test */
     /* Lpar[13], Lpar[14]: first start (100 MHz clock) and migration count; Lpar[15..17]: c, 1 / max(c, 1) and gamma of the request */
 
@@ -319,6 +331,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
     const unsigned hw_slot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4);
     const bool unfavoured = hw_slot != 0u;
+    // SIMD-exclusive long instances.  Two waves share a SIMD, and a pass costs a wave 4.5 us then against 2.4-3.3 us alone -- but a batch ends
+    // when its longest instance does.  So an instance that has run KArgs.excl_min passes asks for its SIMD (one word per SIMD of the chip:
+    // XCC, shader engine / array, CU, SIMD from the hardware id registers; at most KArgs.excl_cap SIMDs are held at a time); while it holds
+    // it, the other wave of that SIMD starts nothing new -- it sleeps at the fetch (and as a helper) until the word is free again.  Only
+    // WHEN an instance runs changes, never its arithmetic.
+    // (Its arguments are read from the kernel-argument segment where they are used -- rare places -- so that they hold no scalar registers across
+    // the loop: every spilled scalar is reloaded through the vector ALU.)
+    const int excl_me = (int)hw_slot + 1;
     const int PS = park_stride(N);
 
     // first round: the queue's head -- the instances that look hardest -- goes to the favoured wave slots; the other
@@ -345,6 +365,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
         if (lane == 0) {
+            {      // the other wave of this SIMD holds it (KArgs.excl): nothing new starts here meanwhile
+                const ExclRef ex_ = excl_ref();
+                while (ex_.word) {
+                    const int v_ = __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v_ == 0 || v_ == excl_me) break;
+                    __builtin_amdgcn_s_sleep(64);
+                }
+            }
             const bool pools = a.park_min > 0 || a.sched_mode > 0;
             if (pools && !unfavoured) { fetched = pool_pop(a, POOL_LONG); from_pool = fetched >= 0; }      // favoured waves: waiting long-runners first
             if (fetched < 0) {
@@ -368,14 +396,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         DynStage dyn;
         // (the instance id goes away BEFORE the tables change and comes back after: a helper still evaluating a cancelled request of the previous
         // instance then finds another id after its evaluation than before it and throws away what it learnt about its window)
-        if (lane == 0) guard_store(Lpar + 19, -1.0);
+        if (lane == 0) ctl_store(ctl + CTL_INST + wid, -1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         prepare_instance<PE, SH>(a, L, a.p + (size_t)inst * a.n_p, te, vref_, dyn);
         *Lvr = vref_;
         WinState ws = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this lane's cross-track window (eval_psi): nothing known yet
         ObsCert oc = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) guard_store(Lpar + 19, (double)inst);         // (helpers tell by it whether their own windows are still this instance's)
+        if (lane == 0) ctl_store(ctl + CTL_INST + wid, inst);         // (helpers tell by it whether their own windows are still this instance's)
         unsigned long long near = ~0ull;            // static circles worth scanning (eval_psi, CULL)
         if constexpr (CULL) {
             near = circle_near_mask(a.p + (size_t)inst * a.n_p, N, shape_nobs<SH>(a), lane, a.cull_radius);
@@ -407,7 +435,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         unsigned fl = 0u;                         // the flags below (FlagBit)
         FlagBit need_grad{fl, 1u << 0}; need_grad = true;
         double cost = 0, gamma = 0, tau = 1, rhs_ls = 0;
-        pk_fbe_u = 0.0;
+        pk_fbe_u = 0.0; pk_hig = 0.0;
         pk_Lc = 0.0; pk_sigma = 0.0; pk_H0 = 1.0;
         FlagBit fbe_ok{fl, 1u << 1};                      // pk_fbe_u holds the FBE at the current iterate (an accepted trial's FBE is the next iteration's: same operands, same bits)
         int iteration = 0, lip_it = 0, ls_n = 0, lb_active = 0, lb_head = 0;
@@ -447,6 +475,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         FlagBit running{fl, 1u << 14}, timed_out{fl, 1u << 15};
         f_start = true; running = true;
         FlagBit posted{fl, 1u << 16};                      // a request of the current iteration is open for the helpers
+        FlagBit excl_held{fl, 1u << 17};                   // this instance holds its SIMD (KArgs.excl)
 #ifdef NMPC_TL
         int tl_it = 0;                            // PANOC steps of this instance so far
 #endif
@@ -479,6 +508,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 pk_Lc *= 2.0; gamma /= 2.0;
                 pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                pk_hig = 0.5 / gamma;
                 NMPC_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
                 lb_batch = true;
@@ -578,11 +608,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 bool exit_now = false;
                 if (__any(norm_r < tol_)) {                    // fpr test, then the AKKT test (opts.akkt_gradient)
                     if (k_akkt == 2) exit_now = true;
-                    else {
+                    else if (k_akkt == 1 && iteration >= 1) {
+                        // grad_prev was copied from grad at the top of this step: the residual r / gamma + grad - grad_prev is r / gamma
+                        exit_now = __any(norm_r < pk_eps_nu * gamma);
+                    } else {
                         const dbl2 q_ = *Lq;
-                        const bool top = k_akkt == 1;       // grad_prev = grad (iteration >= 1) or 0 (iteration 0)
-                        const double b1 = top ? (iteration >= 1 ? 0.0 : gv) : gv - q_.x;
-                        const double b2 = top ? (iteration >= 1 ? 0.0 : gw) : gw - q_.y;
+                        const bool top = k_akkt == 1;       // iteration 0: grad_prev is still the zero vector
+                        const double b1 = top ? gv : gv - q_.x;
+                        const double b2 = top ? gw : gw - q_.y;
                         const double a1 = rv / gamma + b1, a2 = rw / gamma + b2;
                         exit_now = __any(sqrt(group_sum<P>(fma(a1, a1, a2 * a2), lane)) < pk_eps_nu);
                     }
@@ -603,7 +636,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     } else {
                         const double ss = lane_scalar(gU, 10), ys = lane_scalar(gU, 16 + 10);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
-                        if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
+                        if (ok) ok = ys > (LBFGS_CBFGS_EPSILON * norm_r) * ss;      // C-BFGS: <y, s> / ||s||^2 > eps ||r||
                         if (__any(ok)) {
                             took = true;
                             n_take_old = true;
@@ -728,6 +761,20 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             // one the whole batch will end up waiting for.  Raise its wave's issue priority while it shares its SIMD with another
             // wave: worth 1-2 % of the headline batch (39.2 against 39.9 ms without; levels at 1k / 2k / 3k or 0.5k / 1k / 1.5k passes
             // instead of 2k / 4k / 6k: the same within noise) -- the older wave slot is still served first (top of the file).
+            if ((n_pass & 127u) == 0u && !excl_held) {
+                int got_ = 0;
+                if (lane == 0) {
+                    const ExclRef ex_ = excl_ref();
+                    if (ex_.word && n_pass >= (unsigned)ex_.min_passes && __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        if (__hip_atomic_fetch_add(ex_.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ex_.cap) {
+                            int exp_ = 0;
+                            got_ = __hip_atomic_compare_exchange_strong(ex_.word, &exp_, excl_me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                        }
+                        if (!got_) __hip_atomic_fetch_add(ex_.count, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                excl_held = __builtin_amdgcn_readfirstlane(got_) != 0;
+            }
             if (k_dbg == 0 && (n_pass & 1023u) == 0u) {
                 const unsigned lvl = n_pass >> 11;
                 if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
@@ -799,6 +846,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 gamma = GAMMA_L_COEFF / fmax(pk_Lc, MIN_LIPSCHITZ_CONSTANT);
                 pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                pk_hig = 0.5 / gamma;
                 NMPC_HALF_STEP(uv, uw);
                 fbe_ok = false;
                 f_begin = true;
@@ -1000,6 +1048,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                     else y = (fresh_left || long_wait) && alive >= a.sched_long_cap && n_pass - q_pass >= 150u;      // (an outer iteration of a few passes is not worth a hand-over)
                                     dec = (long_now ? 2 : 0);
                                 }
+                                // the other wave of this SIMD holds it (KArgs.excl): out of its way
+                                if (!y && !excl_held) {
+                                    const ExclRef ex_ = excl_ref();
+                                    if (ex_.word && ex_.yield) {
+                                        const int v_ = __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (v_ != 0 && v_ != excl_me) y = 1;
+                                    }
+                                }
                                 // a long-runner on the unfavoured wave slot while favoured waves will still come back for work: hand it over
                                 if (!y && a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min && fresh_left && pool_depth(a, POOL_LONG) < a.park_depth) {
                                     y = 1; cls = POOL_LONG;
@@ -1023,6 +1079,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             NMPC_SEC(pf6);
         }
 
+        if (excl_held) {      // the SIMD goes back (finished or parked)
+            if (lane == 0) {
+                const ExclRef ex_ = excl_ref();
+                __hip_atomic_store(ex_.word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(ex_.count, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            excl_held = false;
+        }
         // ------------------------------------------------------------------ parked: state out, into the pool
         if (parked) {
             double *po = a.park + (size_t)inst * PS;
@@ -1095,18 +1159,23 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // ====================================================================== helper: no work of its own (any more)
     // This wave's slice is free now; it holds the result areas, one per (owner, task).
     if (k_dbg == 0) __builtin_amdgcn_s_setprio(0);
+    // (a sibling may still be evaluating a cancelled request out of this slice: the instance id goes away before the first result area lands in it)
+    if (lane == 0) ctl_store(ctl + CTL_INST + wid, -1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
         if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     WinState ws_h = {te < N - 1 ? te : N - 2, 0.0, 0.0, 0.0};      // this helper lane's cross-track window, valid for the instance `ws_inst`
     ObsCert oc_h = {0.0, 0.0, 0.0, 0, 0, 0};                      // ... and its obstacle certificate, likewise
-    double ws_inst = -1.0;
+    int ws_inst = -1;
     for (;;) {
         if (!k_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
-        // claim the next open task of some sibling's request
+        // claim the next open task of some sibling's request (not on a SIMD the other wave holds: KArgs.excl)
         int got = -1;
-        if (lane == 0) {
+        bool held_ = false;
+        if (lane == 0) { const ExclRef ex_ = excl_ref(); held_ = ex_.word && __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+        if (lane == 0 && !held_) {
             for (int w = 0; w < TEAM_WAVES && got < 0; ++w) {
                 if (w == wid) continue;
                 int v = ctl_load(ctl + CTL_CLAIM + w);
@@ -1141,10 +1210,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         double psi, pen, egv = 0, egw = 0, eav, eaw;
         unsigned long long near_w = ~0ull;
         if constexpr (CULL) { const double nb_ = Lw[mp.par + 18]; near_w = ((unsigned long long)(unsigned)__double2hiint(nb_) << 32) | (unsigned)__double2loint(nb_); }
-        if constexpr (WIN > 0) {            // another instance's reference: what this lane knew about its window is void
-            const double inst_w = guard_load(Lw + mp.par + 19);
+        {                                   // another instance's tables: what this lane knew about its window and its obstacles is void
+            const int inst_w = __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_INST + w));
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
+            if (inst_w != ws_inst || inst_w < 0) { ws_inst = inst_w; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
 #ifdef NMPC_TL
         NMPC_TL_KEEP(zv + zw); NMPC_TL_EV(tl_h, 12);
@@ -1153,18 +1222,18 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #ifdef NMPC_TL
         NMPC_TL_KEEP(psi + egv); NMPC_TL_EV(tl_h, 13);
 #endif
-        if constexpr (WIN > 0) {            // the owner moved on to another instance meanwhile: the scan may have seen half-rewritten tables
+        {                                   // the owner moved on meanwhile: the scans may have seen half-rewritten tables
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (guard_load(Lw + mp.par + 19) != ws_inst) { ws_inst = -1.0; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
+            if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_INST + w)) != ws_inst) { ws_inst = -1; ws_h.mo2 = 0.0; oc_h.m2 = 0.0; }
         }
         // the trial's forward-backward envelope, formed here in the evaluation layout: the tri-layout sums are the same canonical
         // trees as the state layout's (nmpc_device.h), so the value has the bits the owner would compute
-        const double gam_w = Lw[mp.par + 17];
+        const double gam_w = Lw[mp.par + 17], hig_w = Lw[mp.par + 19];
         const double s1_ = fma(-gam_w, egv, zv), s2_ = fma(-gam_w, egw, zw);
         const double e1_ = s1_ - (inea ? clampd(s1_, vmin, vmax) : s1_), e2_ = s2_ - (inea ? clampd(s2_, -wmax, wmax) : s2_);
         const double dist2_ = group_sum<PE>(inea ? fma(e1_, e1_, e2_ * e2_) : 0.0, lane);
         const double gg_ = group_sum<PE>(inea ? fma(egv, egv, egw * egw) : 0.0, lane);
-        const double lhs_ = psi - (0.5 * gam_w) * gg_ + (0.5 * dist2_) / gam_w;
+        const double lhs_ = psi - (0.5 * gam_w) * gg_ + dist2_ * hig_w;
         lds_double *ar = L + (w * 3 + k) * TEAM_AREA_DOUBLES;
         ((lds_double2 *)ar)[24 * q + te] = dbl2{egv, egw};
         if (te == 0) { ar[2 * 72 + q] = psi; ar[2 * 72 + 4 + q] = lhs_; }
@@ -1190,6 +1259,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #undef pk_c_lip
 #undef pk_gr
 #undef pk_fbe_u
+#undef pk_hig
 
 #undef NMPC_FETCH_GRAD
 #undef NMPC_LB_ZERO

@@ -593,12 +593,12 @@ __global__ __launch_bounds__(64) void nmpc_eval2_kernel(KArgs a)
 // the solver: nmpc_solve_hyb.h's state machine on two-stage vectors
 // ---------------------------------------------------------------------------------------------
 // forward-backward envelope at the point whose cost / gradient step / half step / gradient are given (state layout)
-__device__ __forceinline__ double fbe_value2(double cost, double gamma, D2 sv, D2 sw, D2 hv, D2 hw, D2 gv, D2 gw, int lane)
+__device__ __forceinline__ double fbe_value2(double cost, double gamma, double hig, D2 sv, D2 sw, D2 hv, D2 hw, D2 gv, D2 gw, int lane)
 {
     const D2 e1 = sv - hv, e2 = sw - hw;
     double dist2, gg;
     pair_sum(hdot2(e1, e2, e1, e2), hdot2(gv, gw, gv, gw), lane, dist2, gg);
-    return cost - (0.5 * gamma) * gg + (0.5 * dist2) / gamma;
+    return cost - (0.5 * gamma) * gg + dist2 * hig;      // hig = 0.5 / gamma, formed when gamma changes
 }
 
 #define NMPC2_HALF_STEP(xv, xw)                                                                    \
@@ -607,7 +607,7 @@ __device__ __forceinline__ double fbe_value2(double cost, double gamma, D2 sv, D
         hv = D2{ina ? clampd(s1_.a, vmin, vmax) : s1_.a, inb ? clampd(s1_.b, vmin, vmax) : s1_.b}; \
         hw = D2{ina ? clampd(s2_.a, -wmax, wmax) : s2_.a, inb ? clampd(s2_.b, -wmax, wmax) : s2_.b}; \
     } while (0)
-#define NMPC2_FBE(xv, xw) fbe_value2(cost, gamma, fma2(-gamma, gv, (xv)), fma2(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
+#define NMPC2_FBE(xv, xw) fbe_value2(cost, gamma, Lpar[19], fma2(-gamma, gv, (xv)), fma2(-gamma, gw, (xw)), hv, hw, gv, gw, lane)
 // gradient pair of query point K's evaluation, from the LDS area the evaluation lanes have filled (zero beyond the horizon)
 #define NMPC2_LOAD_GRAD(BASE, OV, OW)                                          \
     do {                                                                       \
@@ -679,13 +679,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         const bool resumed = __builtin_amdgcn_readfirstlane(from_pool) != 0;
         if (inst < 0) break;
         long long t_start = (long long)__builtin_amdgcn_s_memrealtime();
-        if (lane == 0) guard_store(Lpar + 19, -1.0);         // (nmpc_solve_hyb.h: the id is away while the tables change)
+        if (lane == 0) ctl_store(ctl + CTL_INST + wid, -1);  // (nmpc_solve_hyb.h: the id is away while the tables change)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         prepare_instance2<SH>(a, L, mp, a.p + (size_t)inst * a.n_p, lane);
         WinState ws[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // this lane's cross-track windows
         ObsCert2 oc = {d2s(0.0), d2s(0.0), d2s(0.0), 0, 0, 0};      // ... and its obstacle certificate
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) guard_store(Lpar + 19, (double)inst); // (helpers tell by it whether their windows are still this instance's)
+        if (lane == 0) ctl_store(ctl + CTL_INST + wid, inst); // (helpers tell by it whether their windows are still this instance's)
 
         // a fresh instance starts from the caller's u0 / y0, a resumed one from its parked state (acquired by pool_pop): u | y | previous gradient
         // in the layout of the caller's arrays, then 16 scalars (park_stride)
@@ -757,6 +757,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 Lc *= 2.0; gamma /= 2.0;
                 sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                Lpar[19] = 0.5 / gamma;      // (the envelope's factor; helpers read it with the request)
                 NMPC2_HALF_STEP(uv, uw);
                 rv = uv - hv; rw = uw - hw;
                 lb_batch = true;
@@ -844,12 +845,14 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 bool exit_now = false;
                 if (__any(norm_r < a.op.tolerance)) {
                     if (a.op.akkt_gradient == 2) exit_now = true;
-                    else {
+                    else if (a.op.akkt_gradient == 1 && iteration >= 1) {
+                        exit_now = __any(norm_r < eps_nu * gamma);      // (nmpc_solve_hyb.h: the residual is r / gamma)
+                    } else {
                         D2 q1, q2;
                         ld4<H2_COLS>(Cq, tc, q1, q2);
-                        const bool top = a.op.akkt_gradient == 1;
-                        const D2 b1 = top ? (iteration >= 1 ? d2s(0.0) : gv) : gv - q1;
-                        const D2 b2 = top ? (iteration >= 1 ? d2s(0.0) : gw) : gw - q2;
+                        const bool top = a.op.akkt_gradient == 1;       // iteration 0: grad_prev is still the zero vector
+                        const D2 b1 = top ? gv : gv - q1;
+                        const D2 b2 = top ? gw : gw - q2;
                         const D2 c1 = D2{rv.a / gamma + b1.a, rv.b / gamma + b1.b}, c2 = D2{rw.a / gamma + b2.a, rw.b / gamma + b2.b};
                         exit_now = __any(sqrt(group_sum<P>(hdot2(c1, c2, c1, c2), lane)) < eps_nu);
                     }
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     } else {
                         const double ss = lane_scalar(gU, 10), ys = lane_scalar(gU, 16 + 10);
                         bool ok = !(ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON);
-                        if (ok) ok = ys / ss > LBFGS_CBFGS_EPSILON * norm_r;
+                        if (ok) ok = ys > (LBFGS_CBFGS_EPSILON * norm_r) * ss;
                         if (__any(ok)) {
                             took = true;
                             n_take_old = true;
@@ -1043,6 +1046,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 gamma = GAMMA_L_COEFF / fmax(Lc, MIN_LIPSCHITZ_CONSTANT);
                 sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
                 c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                Lpar[19] = 0.5 / gamma;      // (the envelope's factor; helpers read it with the request)
                 NMPC2_HALF_STEP(uv, uw);
                 fbe_ok = false;
                 f_begin = true;
@@ -1275,13 +1279,15 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
     }
 
     // ====================================================================== helper: no work of its own (any more)
+    if (lane == 0) ctl_store(ctl + CTL_INST + wid, -1);      // (nmpc_solve_hyb.h: before the first result area lands in this slice)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) {
         if (wid < a.team_owners) ctl_add(ctl + CTL_OWNERS, -1);
         ctl_add(ctl + CTL_HELPERS, 1);
     }
     WinState ws_h[2] = {{2 * te < N - 1 ? 2 * te : N - 2, 0.0, 0.0, 0.0}, {2 * te + 1 < N - 1 ? 2 * te + 1 : N - 2, 0.0, 0.0, 0.0}};      // valid for instance `ws_inst`
     ObsCert2 oc_h = {d2s(0.0), d2s(0.0), d2s(0.0), 0, 0, 0};
-    double ws_inst = -1.0;
+    int ws_inst = -1;
     for (;;) {
         if (!a.team_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
         int got = -1;
@@ -1306,27 +1312,27 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
         ld4<H2_ENT>(rq, te, u1, u2);
         ld4<H2_ENT>(rq + 2 * H2_ENT * 1, te, r1, r2);
         ld4<H2_ENT>(rq + 2 * H2_ENT * (2), te, e1, e2);
-        const double c_w = Lw[mp.par + 15], cbar_w = Lw[mp.par + 16], gam_w = Lw[mp.par + 17];
+        const double c_w = Lw[mp.par + 15], cbar_w = Lw[mp.par + 16], gam_w = Lw[mp.par + 17], hig_w = Lw[mp.par + 19];
         ld4<H2_COLS>((const lds_double2 *)(Lw + mp.vec) + 2 * H2_COLS * (4), te, yv, yw);
         const double tau_w = __hiloint2double((1023 - (2 + 3 * k + q)) << 20, 0), omt_w = 1.0 - tau_w;
         const D2 zv = fma2(-tau_w, e1, fma2(-omt_w, r1, u1)), zw = fma2(-tau_w, e2, fma2(-omt_w, r2, u2));
         double psi, pen;
         D2 egv = d2s(0.0), egw = d2s(0.0), eav, eaw;
         {                                   // another instance's reference: what this lane knew about its windows is void
-            const double inst_w = guard_load(Lw + mp.par + 19);
+            const int inst_w = __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_INST + w));
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (inst_w != ws_inst) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }
+            if (inst_w != ws_inst || inst_w < 0) { ws_inst = inst_w; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }
         }
         eval_psi2<SH, false, NMPC_WIN2>(a, Lw, mp, f2off, lane, te, zv, zw, c_w, cbar_w, yv, yw, true, psi, pen, egv, egw, eav, eaw, ws_h, &oc_h);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (guard_load(Lw + mp.par + 19) != ws_inst) { ws_inst = -1.0; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }      // (the owner moved on meanwhile)
+        if (__builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_INST + w)) != ws_inst) { ws_inst = -1; ws_h[0].mo2 = 0.0; ws_h[1].mo2 = 0.0; oc_h.m2 = d2s(0.0); }      // (the owner moved on meanwhile)
         // the trial's forward-backward envelope, in the evaluation layout (the same canonical sums as the state layout's)
         const D2 s1_ = fma2(-gam_w, egv, zv), s2_ = fma2(-gam_w, egw, zw);
         const D2 x1_ = D2{s1_.a - (inea ? clampd(s1_.a, vmin, vmax) : s1_.a), s1_.b - (ineb ? clampd(s1_.b, vmin, vmax) : s1_.b)};
         const D2 x2_ = D2{s2_.a - (inea ? clampd(s2_.a, -wmax, wmax) : s2_.a), s2_.b - (ineb ? clampd(s2_.b, -wmax, wmax) : s2_.b)};
         const double dist2_ = group_sum<20>((inea ? fma(x1_.a, x1_.a, x2_.a * x2_.a) : 0.0) + (ineb ? fma(x1_.b, x1_.b, x2_.b * x2_.b) : 0.0), lane);
         const double gg_ = group_sum<20>((inea ? fma(egv.a, egv.a, egw.a * egw.a) : 0.0) + (ineb ? fma(egv.b, egv.b, egw.b * egw.b) : 0.0), lane);
-        const double lhs_ = psi - (0.5 * gam_w) * gg_ + (0.5 * dist2_) / gam_w;
+        const double lhs_ = psi - (0.5 * gam_w) * gg_ + dist2_ * hig_w;
         lds_double *ar = L + (w * 3 + k) * TEAM2_AREA_DOUBLES;
         st4<H2_ENT>((lds_double2 *)ar + 2 * H2_ENT * (q), te, egv, egw);
         if (te == 0) { ar[3 * H2_ENT * 4 + q] = psi; ar[3 * H2_ENT * 4 + 4 + q] = lhs_; }

@@ -22,7 +22,7 @@ class OrcOpts(C.Structure):
                 ("sufficient_decrease", C.c_double), ("lbfgs_memory", C.c_int32),
                 ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("max_total_inner", C.c_int32),
                 ("akkt_gradient", C.c_int32), ("ls_failure", C.c_int32), ("inner_status", C.c_int32),
-                ("lbfgs_form", C.c_int32)]
+                ("reserved", C.c_int32)]
 
 
 class OrcStatus(C.Structure):
@@ -66,6 +66,8 @@ class Oracle:
         self.opts = OrcOpts()
         self.lib.orc_default_opts(C.byref(self.opts))
         for k, v in opts.items():
+            if k == "reserved" or not hasattr(self.opts, k):
+                raise TypeError(f"unknown oracle option {k!r}")
             setattr(self.opts, k, v)
         for f in ("orc_n_u", "orc_n_p", "orc_n1", "orc_n2"):
             getattr(self.lib, f).restype = C.c_int
@@ -96,6 +98,17 @@ class Oracle:
         s, c = C.c_double(), C.c_double()
         self.lib.orc_sincos(float(x), C.byref(s), C.byref(c))
         return s.value, c.value
+
+    def lbfgs_gram(self, m, s_list, y_list, r):
+        """H r of the Gram-form L-BFGS after the pairs (s_list[k], y_list[k]), oldest first, entered an empty buffer of memory m."""
+        s_list = np.ascontiguousarray(s_list, dtype=np.float64).reshape(-1, self.n_u)
+        y_list = np.ascontiguousarray(y_list, dtype=np.float64).reshape(-1, self.n_u)
+        d = np.array(r, dtype=np.float64, order="C")
+        self.lib.orc_test_lbfgs_gram.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 3
+        rc = self.lib.orc_test_lbfgs_gram(self.pb.N, int(m), s_list.shape[0], _dp(s_list), _dp(y_list), _dp(d))
+        if rc:
+            raise RuntimeError(f"orc_test_lbfgs_gram failed: {rc}")
+        return d
 
     def tree_sum(self, v):
         v = np.ascontiguousarray(v, dtype=np.float64)

@@ -15,12 +15,19 @@
  *   Every floating-point operation below is written out explicitly (fma() where a fused
  *   multiply-add is meant; the file is compiled with -ffp-contract=off) and all reductions /
  *   scans over the horizon use a fixed, hardware-independent shape:
- *     tree_sum : zero-pad to P (32 for N <= 20, else 64); adjacent-pair binary tree
+ *     tree_sum : zero-pad to P (32 for N <= 20, 64 for 20 < N <= 40); adjacent-pair binary tree
  *     prefix / suffix sums : Kogge-Stone inside blocks of 16 stages, then block carries; for 20 < N <= 40 the
  *                            PAIR form (two consecutive stages are summed first, the Kogge-Stone scan runs over the
  *                            32 pair sums, the first stage of a pair adds its own value to the exclusive result):
  *                            what a kernel that keeps two stages per lane computes (nmpc_solve_hyb2.h)
- *     quarter dot : the inner products of the Gram-form L-BFGS (N <= 40): qdot() below
+ *     quarter dot : the inner products of the Gram-form L-BFGS: qdot() below
+ *   Horizons: 2 <= N <= 40, what the kernels behind include/nmpc_solver.h accept (the reference ships N = 20 and 15, configs/default.yaml:7).
+ *   ONE L-BFGS arithmetic: the Gram form of nmpc_solve_hyb.h / nmpc_solve_hyb2.h (algebraically the two-loop recursion of OpEn's lbfgs
+ *   crate; tests/test_oracle_solver.py holds a numpy two-loop recursion and compares).
+ *   Three formulas are written the cheap way round (same algebra, another rounding):
+ *     - the AKKT residual under akkt_gradient = 1 from iteration 1 on is ||r|| / gamma: tested as ||r|| < eps * gamma;
+ *     - the envelope's last term ||w - u_bar||^2 / (2 gamma) is dist2 * (0.5 / gamma), the factor formed when gamma changes;
+ *     - the C-BFGS safeguard <y, s> / ||s||^2 > eps ||r|| is tested as <y, s> > (eps ||r||) ||s||^2.
  *   so that an implementation on any machine with IEEE-754 f64 add/mul/fma/div/sqrt can
  *   reproduce the results bit for bit.  sin/cos are computed by orc_sincos() (Cody-Waite
  *   reduction + fdlibm kernels written with fma), never by libm.
@@ -36,9 +43,10 @@
 #include <time.h>
 
 #define MAXP 64     /* padded horizon (lanes)        */
+#define MAXN 40     /* longest horizon served (include/nmpc_solver.h) */
 #define MAXOBS 64   /* static circle slots           */
 #define MAXDYN 8    /* dynamic ellipse slots         */
-#define MAXMEM 16   /* L-BFGS memory                 */
+#define MAXMEM 10   /* L-BFGS memory (= GRAM_M: the ring the kernels are built for) */
 #define NZ 20       /* reference configs/default.yaml:35 ; mpc_generator.py:73-75 unpack z0[0..19] */
 
 /* ------------------------------------------------------------------------------------------ */
@@ -257,12 +265,12 @@ void orc_default_opts(orc_opts *o)
     o->akkt_gradient = 1;
     o->ls_failure = 0;
     o->inner_status = 0;
-    o->lbfgs_form = 0;
+    o->reserved = 0;
 }
 
 static int check_problem(const orc_problem *pb)
 {
-    if (pb->N < 2 || pb->N > MAXP) return -1;
+    if (pb->N < 2 || pb->N > MAXN) return -1;
     if (pb->nobs < 0 || pb->nobs > MAXOBS) return -2;
     if (pb->ndyn < 0 || pb->ndyn > MAXDYN) return -3;
     if (!(pb->ts > 0.0)) return -4;
@@ -546,10 +554,9 @@ int orc_eval(const orc_problem *pb, const double *p, const double *u, double c, 
 #define GRAM_M 10      /* pairs the Gram form carries (the hybrid kernel's ring): ages >= m, and inactive ages, are exactly zero */
 /* stages the quarter dot runs over (zero padded): 20 for N <= 20 (nmpc_solve_hyb.h), 40 for 20 < N <= 40 (nmpc_solve_hyb2.h) */
 #define GRAM_NST(N) ((N) <= 20 ? 20 : 40)
-#define GRAM_SERVES(N) ((N) <= 40)
 typedef struct {
     int m, active, first_old;
-    int gram;                      /* > 0: the Gram form below, over this many stages (what nmpc_solve_hyb.h / nmpc_solve_hyb2.h compute); 0: the two-loop recursion */
+    int gram;                      /* stages the quarter dots run over (GRAM_NST): what nmpc_solve_hyb.h / nmpc_solve_hyb2.h compute */
     hvec S[MAXMEM], Y[MAXMEM];     /* index 0 = newest */
     double rho[MAXMEM];
     double H0;
@@ -561,7 +568,7 @@ typedef struct {
 typedef struct {
     hvec g, gs, uh, r, d, up, gprev;   /* gradient, gradient step, half step, gamma*fpr, direction, u_plus */
     hvec gk;                           /* gradient at the current iterate, kept through the line search (ls_failure = 1) */
-    double cost, L, gamma, sigma, nr2, norm_r, tau;
+    double cost, L, gamma, hig, sigma, nr2, norm_r, tau;      /* hig = 0.5 / gamma, formed when gamma changes */
     int iteration;
     lbfgs_t lb;
     uint32_t n_cost, n_grad;
@@ -591,18 +598,39 @@ static void grad_and_half_step(const inst_t *I, panoc_t *c, const hvec *x)
 static void compute_fpr(const inst_t *I, panoc_t *c, const hvec *u)
 {
     for (int t = 0; t < I->P; ++t) { c->r.v[t] = u->v[t] - c->uh.v[t]; c->r.w[t] = u->w[t] - c->uh.w[t]; }
-    c->nr2 = c->lb.gram ? qdot(&c->r, &c->r, c->lb.gram) : hdot(&c->r, &c->r, I->P);
+    c->nr2 = qdot(&c->r, &c->r, c->lb.gram);
     c->norm_r = sqrt(c->nr2);
 }
 
 static void lbfgs_reset(lbfgs_t *lb)
 {
     lb->active = 0; lb->first_old = 1;
-    if (lb->gram) {      /* the Gram form runs over all GRAM_M ages every time: what is not active is exactly zero */
-        memset(lb->S, 0, sizeof(hvec) * GRAM_M); memset(lb->Y, 0, sizeof(hvec) * GRAM_M);
-        memset(lb->rho, 0, sizeof(double) * GRAM_M);
-        memset(lb->SY, 0, sizeof(lb->SY)); memset(lb->YY, 0, sizeof(lb->YY));
+    /* the Gram form runs over all GRAM_M ages every time: what is not active is exactly zero */
+    memset(lb->S, 0, sizeof(hvec) * GRAM_M); memset(lb->Y, 0, sizeof(hvec) * GRAM_M);
+    memset(lb->rho, 0, sizeof(double) * GRAM_M);
+    memset(lb->SY, 0, sizeof(lb->SY)); memset(lb->YY, 0, sizeof(lb->YY));
+}
+
+/* the pair (s, y), <y, s> = ys, enters the buffer as its newest (age 0); every other pair ages by one, the oldest leaves */
+static void lbfgs_push(lbfgs_t *lb, const hvec *s, const hvec *y, double ys)
+{
+    for (int k = lb->m - 1; k > 0; --k) { lb->S[k] = lb->S[k - 1]; lb->Y[k] = lb->Y[k - 1]; lb->rho[k] = lb->rho[k - 1]; }
+    lb->S[0] = *s;
+    lb->Y[0] = *y;
+    lb->rho[0] = 1.0 / ys;
+    /* the new pair's column of SY and row / column of YY are measured against the pairs that stay.
+     * (Each entry is a function of two stored vectors only, so keeping it equals recomputing it.) */
+    for (int a = lb->m - 1; a > 0; --a)
+        for (int b = lb->m - 1; b > 0; --b) { lb->SY[a][b] = lb->SY[a - 1][b - 1]; lb->YY[a][b] = lb->YY[a - 1][b - 1]; }
+    for (int a = 1; a < lb->m; ++a) {
+        lb->SY[a][0] = qdot(&lb->S[a], y, lb->gram);
+        lb->SY[0][a] = 0.0;
+        lb->YY[a][0] = lb->YY[0][a] = qdot(&lb->Y[a], y, lb->gram);
     }
+    lb->SY[0][0] = 0.0;
+    lb->YY[0][0] = qdot(y, y, lb->gram);
+    lb->H0 = ys / lb->YY[0][0];
+    if (lb->active < lb->m) lb->active++;
 }
 
 /* lbfgs crate: update_hessian(g := gamma_fpr, s := u) with sy-epsilon and C-BFGS safeguards */
@@ -615,34 +643,15 @@ static void lbfgs_update(const inst_t *I, lbfgs_t *lb, const hvec *r, const hvec
         s.v[t] = u->v[t] - lb->old_s.v[t]; s.w[t] = u->w[t] - lb->old_s.w[t];
         y.v[t] = r->v[t] - lb->old_g.v[t]; y.w[t] = r->w[t] - lb->old_g.w[t];
     }
-    const double ys = lb->gram ? qdot(&s, &y, lb->gram) : hdot(&s, &y, P), ss = lb->gram ? qdot(&s, &s, lb->gram) : hdot(&s, &s, P);
+    const double ys = qdot(&s, &y, lb->gram), ss = qdot(&s, &s, lb->gram);
     if (ss <= DBL_MIN || ys <= LBFGS_SY_EPSILON) return;
-    if (!(ys / ss > LBFGS_CBFGS_EPSILON * norm_r)) return;
+    if (!(ys > (LBFGS_CBFGS_EPSILON * norm_r) * ss)) return;      /* C-BFGS: <y, s> / ||s||^2 > eps ||r||^alpha, alpha = 1 */
     lb->old_s = *u;
     lb->old_g = *r;
-    for (int k = lb->m - 1; k > 0; --k) { lb->S[k] = lb->S[k - 1]; lb->Y[k] = lb->Y[k - 1]; lb->rho[k] = lb->rho[k - 1]; }
-    lb->S[0] = s;
-    lb->Y[0] = y;
-    lb->rho[0] = 1.0 / ys;
-    if (lb->gram) {
-        /* every pair ages by one; the new pair's column of SY and row / column of YY are measured against the pairs that stay.
-         * (Each entry is a function of two stored vectors only, so keeping it equals recomputing it.) */
-        for (int a = lb->m - 1; a > 0; --a)
-            for (int b = lb->m - 1; b > 0; --b) { lb->SY[a][b] = lb->SY[a - 1][b - 1]; lb->YY[a][b] = lb->YY[a - 1][b - 1]; }
-        for (int a = 1; a < lb->m; ++a) {
-            lb->SY[a][0] = qdot(&lb->S[a], &y, lb->gram);
-            lb->SY[0][a] = 0.0;
-            lb->YY[a][0] = lb->YY[0][a] = qdot(&lb->Y[a], &y, lb->gram);
-        }
-        lb->SY[0][0] = 0.0;
-        lb->YY[0][0] = qdot(&y, &y, lb->gram);
-        lb->H0 = ys / lb->YY[0][0];
-    } else
-    lb->H0 = ys / hdot(&y, &y, P);
-    if (lb->active < lb->m) lb->active++;
+    lbfgs_push(lb, &s, &y, ys);
 }
 
-/* d := H d in the Gram form (N <= 20; nmpc_solve_hyb.h): the coefficients of the two-loop recursion,
+/* d := H d in the Gram form (nmpc_solve_hyb.h, nmpc_solve_hyb2.h): the coefficients of the two-loop recursion,
  *   alpha_j = rho_j <s_j, q_j>,  beta_j = rho_j <y_j, z_j>,
  * come out of two recurrences over the inner products <s_k, r>, <y_k, r>, SY, YY instead of twenty dependent reductions over the
  * horizon; the vector updates are those of the two-loop recursion, in its order.  All GRAM_M ages take part every time (what is
@@ -670,23 +679,32 @@ static void lbfgs_apply_gram(const inst_t *I, const lbfgs_t *lb, hvec *d)
     }
 }
 
-/* two-loop recursion, q := H q */
-static void lbfgs_apply(const inst_t *I, const lbfgs_t *lb, hvec *q)
+/* test hook (tests/test_oracle_solver.py compares with a two-loop recursion written in numpy): `npush` pairs (s, y) -- [npush][2 N],
+ * (v, w) interleaved by stage, oldest first -- enter an empty buffer of memory m without the safeguards; d_io: in r, out H r */
+int orc_test_lbfgs_gram(int N, int m, int npush, const double *s_list, const double *y_list, double *d_io)
 {
-    const int P = I->P;
-    double alpha[MAXMEM];
-    if (lb->active == 0) return;
-    for (int k = 0; k < lb->active; ++k) {
-        const double a = lb->rho[k] * hdot(&lb->S[k], q, P);
-        alpha[k] = a;
-        for (int t = 0; t < P; ++t) { q->v[t] = fma(-a, lb->Y[k].v[t], q->v[t]); q->w[t] = fma(-a, lb->Y[k].w[t], q->w[t]); }
+    if (N < 2 || N > MAXN || m < 1 || m > GRAM_M || npush < 0) return -1;
+    inst_t *I = (inst_t *)calloc(1, sizeof(inst_t));
+    lbfgs_t *lb = (lbfgs_t *)calloc(1, sizeof(lbfgs_t));
+    I->N = N; I->P = horizon_pad(N);
+    lb->m = m; lb->gram = GRAM_NST(N);
+    lbfgs_reset(lb);
+    for (int k = 0; k < npush; ++k) {
+        hvec s, y;
+        memset(&s, 0, sizeof s); memset(&y, 0, sizeof y);
+        for (int t = 0; t < N; ++t) {
+            s.v[t] = s_list[(size_t)k * 2 * N + 2 * t]; s.w[t] = s_list[(size_t)k * 2 * N + 2 * t + 1];
+            y.v[t] = y_list[(size_t)k * 2 * N + 2 * t]; y.w[t] = y_list[(size_t)k * 2 * N + 2 * t + 1];
+        }
+        lbfgs_push(lb, &s, &y, qdot(&s, &y, lb->gram));
     }
-    for (int t = 0; t < P; ++t) { q->v[t] = lb->H0 * q->v[t]; q->w[t] = lb->H0 * q->w[t]; }
-    for (int k = lb->active - 1; k >= 0; --k) {
-        const double b = lb->rho[k] * hdot(&lb->Y[k], q, P);
-        const double ab = alpha[k] - b;
-        for (int t = 0; t < P; ++t) { q->v[t] = fma(ab, lb->S[k].v[t], q->v[t]); q->w[t] = fma(ab, lb->S[k].w[t], q->w[t]); }
-    }
+    hvec d;
+    memset(&d, 0, sizeof d);
+    for (int t = 0; t < N; ++t) { d.v[t] = d_io[2 * t]; d.w[t] = d_io[2 * t + 1]; }
+    lbfgs_apply_gram(I, lb, &d);
+    for (int t = 0; t < N; ++t) { d_io[2 * t] = d.v[t]; d_io[2 * t + 1] = d.w[t]; }
+    free(lb); free(I);
+    return 0;
 }
 
 /* forward-backward envelope at the point whose cost/gradient/gs/uh are in the cache */
@@ -699,7 +717,7 @@ static double fbe(const inst_t *I, const panoc_t *c)
     }
     const double dist2 = tree_sum_p(t, I->P);
     const double gg = hdot(&c->g, &c->g, I->P);
-    return c->cost - (0.5 * c->gamma) * gg + (0.5 * dist2) / c->gamma;
+    return c->cost - (0.5 * c->gamma) * gg + dist2 * c->hig;
 }
 
 static void do_eval(const inst_t *I, panoc_t *c, const hvec *x, double pen, const hvec *y, int want_grad,
@@ -742,6 +760,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         c->L = sqrt(hdot(&dg, &dg, P)) / norm_h;
     }
     c->gamma = GAMMA_L_COEFF / dmax(c->L, MIN_LIPSCHITZ_CONSTANT);
+    c->hig = 0.5 / c->gamma;
     c->sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * c->gamma);
     grad_and_half_step(I, c, u);
     c->passes3++; c->passes6++;       /* u and u + h in one pass */
@@ -753,14 +772,17 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         compute_fpr(I, c, u);
         if (c->norm_r < tol) {           /* fpr test, then the AKKT test (short-circuit) */
             if (opts->akkt_gradient == 2) break;                 /* no AKKT test */
+            if (opts->akkt_gradient == 1 && c->iteration >= 1) {
+                /* grad_prev was copied from grad at the top of this step: the difference is exactly zero and the residual is ||r|| / gamma */
+                if (c->norm_r < akkt_tol * c->gamma) break;
+            } else {
             double t[MAXP];
             for (int j = 0; j < P; ++j) {
                 double a, b;
                 if (opts->akkt_gradient == 1) {
-                    /* grad_prev was copied from grad at the top of this step (iteration >= 1: the
-                     * difference is exactly zero) or is still the zero vector (iteration 0) */
-                    a = c->r.v[j] / c->gamma + (c->iteration >= 1 ? 0.0 : c->g.v[j]);
-                    b = c->r.w[j] / c->gamma + (c->iteration >= 1 ? 0.0 : c->g.w[j]);
+                    /* iteration 0: grad_prev is still the zero vector */
+                    a = c->r.v[j] / c->gamma + c->g.v[j];
+                    b = c->r.w[j] / c->gamma + c->g.w[j];
                 } else {
                     a = c->r.v[j] / c->gamma + (c->g.v[j] - c->gprev.v[j]);
                     b = c->r.w[j] / c->gamma + (c->g.w[j] - c->gprev.w[j]);
@@ -768,18 +790,20 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
                 t[j] = fma(a, a, b * b);
             }
             if (sqrt(tree_sum_p(t, P)) < akkt_tol) break;
+            }
         }
         /* Lipschitz / gamma backtracking */
         do_eval(I, c, &c->uh, pen, y, 0, o);
         double cost_uh = o->psi;
         int n_back = 0, n_trials = 0;
         for (int it = 0; it < MAX_LIPSCHITZ_UPDATE_ITERATIONS && c->L < MAX_LIPSCHITZ_CONSTANT; ++it) {
-            const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - (c->lb.gram ? qdot(&c->g, &c->r, c->lb.gram) : hdot(&c->g, &c->r, P))
+            const double rhs = c->cost + LIPSCHITZ_UPDATE_EPSILON * fabs(c->cost) - qdot(&c->g, &c->r, c->lb.gram)
                              + (GAMMA_L_COEFF / (2.0 * c->gamma)) * c->nr2;
             if (!(cost_uh > rhs)) break;
             lbfgs_reset(&c->lb);
             c->L *= 2.0;
             c->gamma /= 2.0;
+            c->hig = 0.5 / c->gamma;
             grad_and_half_step(I, c, u);
             do_eval(I, c, &c->uh, pen, y, 0, o);
             cost_uh = o->psi;
@@ -789,7 +813,7 @@ static int panoc_solve(const inst_t *I, const orc_opts *opts, panoc_t *c, hvec *
         c->sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * c->gamma);
         /* L-BFGS buffer update and direction */
         lbfgs_update(I, &c->lb, &c->r, u, c->norm_r);
-        if (c->iteration > 0) { c->d = c->r; if (c->lb.gram) lbfgs_apply_gram(I, &c->lb, &c->d); else lbfgs_apply(I, &c->lb, &c->d); }
+        if (c->iteration > 0) { c->d = c->r; lbfgs_apply_gram(I, &c->lb, &c->d); }
         if (c->iteration == 0) {
             /* first iteration: plain forward-backward step */
             *u = c->uh;
@@ -865,7 +889,7 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
 {
     int rc = check_problem(pb);
     if (rc) return rc;
-    if (opts->lbfgs_memory < 1 || opts->lbfgs_memory > MAXMEM) return -5;
+    if (opts->lbfgs_memory < 1 || opts->lbfgs_memory > GRAM_M) return -5;
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const int N = pb->N;
@@ -875,9 +899,7 @@ int orc_solve(const orc_problem *pb, const orc_opts *opts, const double *p, doub
     prepare(pb, p, I);
     const int P = I->P, n2 = pb->nobs + pb->ndyn;
     pc->lb.m = opts->lbfgs_memory;
-    /* the L-BFGS arithmetic follows the kernel that solves this horizon: Gram form for N <= 40 (nmpc_solve_hyb.h, nmpc_solve_hyb2.h),
-     * the two-loop recursion for the one-point kernel (N > 40); opts->lbfgs_form = 1 forces the two-loop recursion (tests compare the two) */
-    pc->lb.gram = (GRAM_SERVES(N) && opts->lbfgs_memory <= GRAM_M && opts->lbfgs_form != 1) ? GRAM_NST(N) : 0;
+    pc->lb.gram = GRAM_NST(N);
     hvec u, y, yplus;
     load_hvec(&u, u_io, N, 1);
     load_hvec(&y, y0, N, 0);

@@ -61,8 +61,7 @@ typedef struct orc_opts {
                                   1 tau = 0: plain forward-backward step from the current iterate             */
     int32_t inner_status;      /* outer criteria hold: 0 report the last inner solve's status,
                                   1 report Converged                                                          */
-    int32_t lbfgs_form;        /* ORACLE ONLY (the kernels have one form per horizon): 0 the form of the kernel that solves this
-                                  horizon -- Gram form for N <= 40, two-loop recursion for N > 40; 1 the two-loop recursion always */
+    int32_t reserved;
 } orc_opts;
 
 typedef struct orc_status {
@@ -105,6 +104,8 @@ int orc_solve_batch(const orc_problem *pb, const orc_opts *opts, int B, const do
 void orc_sincos(double x, double *s, double *c);
 void orc_sincos_n(int n, const double *x, double *s, double *c);     /* the same, element by element */
 double orc_tree_sum(const double *v, int n);
+/* the Gram-form L-BFGS alone (tests compare it with a two-loop recursion): npush pairs enter an empty buffer of memory m, d_io: r -> H r */
+int orc_test_lbfgs_gram(int N, int m, int npush, const double *s_list, const double *y_list, double *d_io);
 
 #ifdef __cplusplus
 }

@@ -28,8 +28,11 @@ ap.add_argument("--split", type=int, default=2,
 ap.add_argument("--budget", type=int, default=0,
                 help="max_total_inner per solve: the deterministic counterpart of the reference's 0.5 s max_duration "
                      "(src/mpc/mpc_generator.py:9,186); 0 = off")
+ap.add_argument("--experiments", action="store_true", help="the experiments build of the library (reads the NMPC_* knobs: A/B runs only)")
 args = ap.parse_args()
 sopts = {"max_total_inner": args.budget} if args.budget > 0 else {}
+if args.experiments:
+    sopts["experiments"] = True
 cfg = named_config("cfg4")
 route = harness.scene_route(cfg, args.scene)
 rng = np.random.Generator(np.random.PCG64(0))

@@ -42,9 +42,7 @@ def test_sizes_and_struct_layout():
 def test_oracle_and_abi_share_option_fields():
     """The test oracle's option struct mirrors nmpc_opts field for field (the parity tests pass one dict to both)."""
     from oracle.binding import OrcOpts
-    # (the last slot is `reserved` in the ABI; the oracle uses it for its own lbfgs_form switch, which no kernel has)
-    assert [f for f, _ in OrcOpts._fields_][:-1] == [f for f, _ in _lib.NmpcOpts._fields_][:-1]
-    assert OrcOpts._fields_[-1][0] == "lbfgs_form" and _lib.NmpcOpts._fields_[-1][0] == "reserved"
+    assert [f for f, _ in OrcOpts._fields_] == [f for f, _ in _lib.NmpcOpts._fields_]
     assert ctypes.sizeof(OrcOpts) == ctypes.sizeof(_lib.NmpcOpts)
 
 

@@ -108,13 +108,13 @@ def test_solve_nobs50_and_dynamic_obstacles(solvers):
 
 
 SHAPES = [(20, 10, 2), (20, 0, 0), (19, 10, 3), (17, 4, 1), (16, 0, 0), (15, 3, 2), (5, 1, 3), (2, 0, 0),
-          (21, 10, 3), (32, 64, 3), (33, 10, 3), (34, 0, 0), (37, 3, 1), (39, 12, 2), (40, 4, 3), (41, 10, 3), (64, 3, 0)]
+          (21, 10, 3), (32, 64, 3), (33, 10, 3), (34, 0, 0), (37, 3, 1), (39, 12, 2), (40, 4, 3), (40, 64, 0), (36, 0, 3)]
 
 
 @pytest.mark.parametrize("N,nobs,ndyn", SHAPES)
 def test_shape_sweep_bit_exact(N, nobs, ndyn):
-    """Every lane layout (three / two / one query point per wave; one and two stages per lane) with full and partial horizons,
-    padded and empty obstacle tables: cost layer and solve against the oracle, bit for bit."""
+    """Every accepted horizon class (one and two stages per lane, the shape-specialised and the run-time-shape kernels) with full and
+    partial horizons, padded and empty obstacle tables: cost layer and solve against the oracle, bit for bit."""
     from mpc_trajectory_generator_amd.config import load_config
     from mpc_trajectory_generator_amd.solver import BatchSolver
     cfg = load_config(N_hor=N, Nobs=nobs, Ndynobs=ndyn)
@@ -161,14 +161,14 @@ def test_alternative_kernels_same_bits(monkeypatch, name, env, kernel):
 
 
 # restatement switches (include/nmpc_solver.h): every value of every switch, alone and
-# combined, in every solve kernel -- hybrid (N <= 20), two-stage hybrid (20 < N <= 40; N = 24 the run-time shape, 40 the specialised one), one-point (N > 40)
+# combined, in every solve kernel -- hybrid (N <= 20), two-stage hybrid (20 < N <= 40; N = 24 and 33 the run-time shape, 40 the specialised one)
 SWITCHES = [dict(akkt_gradient=0), dict(akkt_gradient=2), dict(ls_failure=1), dict(inner_status=1),
             dict(akkt_gradient=0, ls_failure=1, inner_status=1), dict(max_total_inner=150),
             dict(max_total_inner=700, ls_failure=1, akkt_gradient=0), dict(lbfgs_memory=7), dict(lbfgs_memory=2)]
 
 
 @pytest.mark.parametrize("opts", SWITCHES, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
-@pytest.mark.parametrize("N", [20, 24, 40, 48])
+@pytest.mark.parametrize("N", [20, 24, 40, 33])
 def test_restatement_switches_bit_exact(N, opts):
     from mpc_trajectory_generator_amd.config import load_config
     from mpc_trajectory_generator_amd.solver import BatchSolver
@@ -204,8 +204,8 @@ def test_line_search_exhaustion_paths_are_exercised():
 @pytest.mark.parametrize("m", [1, 5])
 @pytest.mark.parametrize("N", [20, 24, 40])
 def test_short_lbfgs_memory_bit_exact(N, m):
-    """lbfgs_memory < 10: the general (ring-buffer) two-loop code of every kernel, and no LDS write past the
-    ring (the zero column of the hybrid kernel is per allocated slot)."""
+    """lbfgs_memory < 10: the pair that reaches age m leaves the ring (its slot, its products and its rho go back to zero), and no LDS
+    write lands past the ring (the zero column of the hybrid kernel is per allocated slot)."""
     from mpc_trajectory_generator_amd.config import load_config
     from mpc_trajectory_generator_amd.solver import BatchSolver
     cfg = load_config(N_hor=N)
@@ -406,7 +406,7 @@ def test_batched_receding_horizon_on_gpu_equals_oracle(solvers):
 
 
 def test_fuzz_shapes_and_options():
-    """scripts/fuzz_parity.py: random shapes (all three solve kernels) x random solver options and restatement switches x
+    """scripts/fuzz_parity.py: random shapes (both solve kernels, shape-specialised and run-time-shape) x random solver options and restatement switches x
     random small batches, cold and warm-started with user penalties -- every case bit-identical to the oracle."""
     import os
     import subprocess
@@ -670,3 +670,13 @@ def test_results_do_not_depend_on_timing():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stress_teams.py"), "6"], capture_output=True, text=True,
                        cwd=ROOT, timeout=900)
     assert r.returncode == 0 and "STRESS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_horizon_beyond_forty_is_refused():
+    """include/nmpc_solver.h: NMPC_MAX_HORIZON = 40 -- one L-BFGS arithmetic and one set of certificates behind the ABI."""
+    from mpc_trajectory_generator_amd.config import load_config
+    from mpc_trajectory_generator_amd.solver import BatchSolver, SolverError
+    for N in (41, 48, 64):
+        with pytest.raises(SolverError) as e:
+            BatchSolver(load_config(N_hor=N), max_batch=4)
+        assert e.value.code == -1
