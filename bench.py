@@ -123,6 +123,38 @@ def pmc_traffic(kernel_name, config, B, routes):
     return None, None
 
 
+def pmc_valu(kernel_name, config):
+    """Vector instructions per evaluation pass and the vector ALU's busy share from the SQ counter pass (profiles/*/valu.json), keyed like the
+    PMC traffic by kernel + source hash + config; None if not measured for these sources."""
+    import glob
+    from mpc_trajectory_generator_amd import _lib
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu.json")), reverse=True):
+        try:
+            entries = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in entries:
+            if e.get("kernel") == kernel_name and e.get("config") == config and e.get("source_hash") == _lib.source_hash():
+                return e, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def dynamic_mix(kernel_name, config):
+    """Executed instructions per evaluation pass by class (scripts/bbcount.py: basic-block counters in the compiler's own assembly), from
+    profiles/*/dynamic_mix.json, keyed by kernel + source hash + config; None if not measured for these sources."""
+    import glob
+    from mpc_trajectory_generator_amd import _lib
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "dynamic_mix.json")), reverse=True):
+        try:
+            entries = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for e in entries if isinstance(entries, list) else [entries]:
+            if e.get("kernel") == kernel_name and e.get("config") == config and e.get("source_hash") == _lib.source_hash() and e.get("instance") is None:
+                return {k: e.get(k) for k in ("per_pass", "valu_per_pass", "f64_share_of_valu", "all_instructions_per_pass")}, os.path.relpath(path, ROOT)
+    return None, None
+
+
 def scan_shares(kernel_name, config):
     """Share of the evaluations in which the exact certificates of eval_psi fell back to the full cross-track scan / ran the obstacle
     activity scan (counters of a -DNMPC_WIN_STATS build, scripts/win_stats.py -> profiles/*/scan_shares.json), keyed like the PMC traffic

@@ -2,6 +2,8 @@
 neither the compiler nor its machine verifier reports.  `verify()` compiles csrc/nmpc_kernels.hip once more with the
 flags of the real build plus machine-code dumps and checks
 
+The third check reads the final assembly: every DPP read keeps its two wait states from the last vector write of its source (check_dpp_hazards).
+
 1. the machine scheduler: every virtual-register lane an instruction reads must come from the same defining instruction after scheduling
    as before it.  (-amdgpu-sched-strategy=max-ilp hoisted the lane copy `%X.sub1 = COPY %X.sub3` that feeds the second operand of a
    v_permlane32_swap above the `V_ADD_F64` producing its source, because the register coalescer had left a read-undef flag on the swap's tied
@@ -189,6 +191,70 @@ def check_exec_restores(text):
     return nfun, nrestore, hits
 
 
+# ------------------------------------------------------------------------------------------------- 3. DPP reads behind inline asm
+def _vregs(tok):
+    """vector registers an operand names: 'v5' -> {5}, 'v[4:5]' -> {4, 5}; anything else -> {}"""
+    m = re.match(r"^-?\|?v(\d+)\|?$", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.match(r"^-?\|?v\[(\d+):(\d+)\]\|?$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def check_dpp_hazards(asm_text):
+    """A DPP instruction reads its first source from OTHER lanes' registers: the hardware needs two wait states between a vector-ALU write
+    of that register and the read, and does not interlock.  The compiler inserts them for its own instructions but cannot see into an asm
+    statement -- and this library's DPP arithmetic (v_fmac_f64_dpp row_newbcast) and its EXEC windows live in asm statements.  So every DPP
+    read of the FINAL code is checked: no vector write of its DPP source within the two preceding wait states (s_nop N counts N + 1; a
+    branch target or a branch ends the look-back: the compiler's own nops cover its control-flow edges).  -> (dpp instructions, violations)"""
+    ndpp, bad = 0, []
+    fn = None
+    hist = []           # (wait states the instruction occupies, registers it writes if it is a vector-ALU instruction)
+    for raw in asm_text.split("\n"):
+        t = raw.strip()
+        m = re.match(r"^(_Z\w+|nmpc_\w+):", t)
+        if m:
+            fn, hist = m.group(1), []
+            continue
+        if t.startswith(".Lfunc_end"):
+            fn = None
+            continue
+        if fn is None or not t or t.startswith(";") or t.startswith("."):
+            if fn and re.match(r"^\.LBB\d+_\d+:", t):
+                hist = []
+            continue
+        t = re.sub(r"\s*;.*$", "", t)
+        op = t.split()[0]
+        ops = [x.strip() for x in t[len(op):].split(",")]
+        if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):
+            hist = []
+            continue
+        if op.endswith("_dpp") or " row_" in t or " quad_perm" in t or " wave_sh" in t or " row_newbcast" in t:
+            ndpp += 1
+            src = _vregs(ops[1].split()[0]) if len(ops) > 1 else set()
+            ws = 0
+            for states, wr in reversed(hist):
+                if ws >= 2:
+                    break
+                if wr & src:
+                    bad.append((fn, t[:120]))
+                    break
+                ws += states
+        if op == "s_nop":
+            hist.append((int(ops[0], 0) + 1, set()))
+        elif op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+            wr = _vregs(ops[0].split()[0])
+            if op.startswith("v_permlane") and len(ops) > 1:      # the swaps rewrite both operands
+                wr |= _vregs(ops[1].split()[0])
+            hist.append((1, wr))
+        else:
+            hist.append((1, set()))
+        hist = hist[-4:]
+    return ndpp, bad
+
+
 # ------------------------------------------------------------------------------------------------- driver
 def makefile_flags():
     """the code-generation flags csrc/Makefile builds with (its scheduler strategy)"""
@@ -229,18 +295,21 @@ def verify(flags=None, src=None):
             e.close()
         if any(rcs):
             return {"ok": False, "flags": flags, "error": (texts[0][-1500:] + texts[1][-1500:])}
-        resources = kernel_resources(open(os.path.join(td, "x.s")).read())
+        asm_text = open(os.path.join(td, "x.s")).read()
+        resources = kernel_resources(asm_text)
+    ndpp, dpp_bad = check_dpp_hazards(asm_text)
     stats, bad, latent = check_scheduler(texts[0])
     nfun, nrestore, hits = check_exec_restores(texts[1])
     # strategies that move instructions between blocks (the default one rematerialises) are outside what check 1 can compare
     moved = [b for b in bad if b[2] == "instruction set of the block changed"]
     bad = [b for b in bad if b[2] != "instruction set of the block changed"]
-    return {"ok": not bad and not latent and not hits, "flags": flags, "kernels": len(stats), "instructions": sum(s[2] for s in stats),
+    return {"ok": not bad and not latent and not hits and not dpp_bad, "flags": flags, "dpp_reads": ndpp, "dpp_hazards": len(dpp_bad), "kernels": len(stats), "instructions": sum(s[2] for s in stats),
             "blocks_not_comparable": len(moved), "sched_changed": len(bad), "sched_latent": len(latent), "exec_restores": nrestore,
             "exec_hits": len(hits),
             "details": [f"{b[0][:60]} block {b[1]}: {b[2]} {b[3]}" for b in bad[:8]] +
                        [f"latent {l[0][:60]} block {l[1]}: {l[3]} read by {l[2]}" for l in latent[:8]] +
-                       [f"exec {h[0][:60]} {h[1]}: {h[2]}" for h in hits[:8]],
+                       [f"exec {h[0][:60]} {h[1]}: {h[2]}" for h in hits[:8]] +
+                       [f"dpp {h[0][:60]}: {h[1]}" for h in dpp_bad[:8]],
             "resources": resources}
 
 

@@ -38,7 +38,6 @@ constexpr int TEAM_REQ_DOUBLES = 3 * 24 * 2;
 constexpr int TEAM_AREA_DOUBLES = 3 * 24 * 2 + 8;     // + psi[3], envelope[3]
 constexpr int TEAM_CTL_INTS = 64;
 // instances waiting for a wave (nmpc_solve_hyb.h): long = an outer criterion is still open after the outer iteration just finished, cold = all hold: the next outer iteration is the last (and short)
-constexpr int EXCL_KEYS = 8192;      // (XCC, SE / SH, CU, SIMD) of a wave as one index: KArgs.excl
 constexpr int NPOOLS = 2;
 enum { POOL_LONG = 0, POOL_COLD = 1 };
 
@@ -102,11 +101,6 @@ struct KArgs {
     int team_owners;           // hybrid kernel: waves per workgroup that take instances from the queue (1..4); the others only help
     int team_help;             // 0: nobody asks for help (experiments, NMPC_TEAM_HELP=0: the single-wave baseline)
     double cull_radius;        // eval_psi's CULL path: circles whose edge is farther than this from the start position are left out of the scan
-    // SIMD-exclusive long instances (nmpc_solve_hyb.h), NULL = off: one word per SIMD of the chip (the wave slot + 1 that holds it, 0 = free), then the number held
-    int *excl;
-    int excl_min;              // passes after which an instance asks for its SIMD
-    int excl_cap;              // SIMDs that may be held at a time
-    int excl_yield;            // 1: the other wave of a held SIMD parks its instance at the next outer-iteration boundary
     // eval kernel only
     const double *ev_c;
     const double *ev_y;
@@ -944,8 +938,6 @@ struct nmpc_handle {
     double *d_park;            // parked solver states, allocated on first use
     int *d_pool;
     unsigned int *d_pool_ctr;
-    int *d_excl;               // SIMD-exclusive long instances: KArgs.excl
-    int excl_min, excl_cap, excl_yield;
     bool loop_order_prev;      // nmpc_loop_step: launch order from the previous step's pass counts (experiments: NMPC_LOOP_ORDER_PREV=0 switches it off)
     int *d_order;              // launch order (hard-looking instances first)
     bool use_order;
@@ -1047,9 +1039,8 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
 #endif
     h->map = make_map(*pb, h->P == 40 ? 64 : h->P);      // (P = 40: the kernels compute their own map, nmpc_solve_hyb2.h)
     h->d_queue = nullptr;
-    h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr; h->d_excl = nullptr;
+    h->d_park = nullptr; h->d_pool = nullptr; h->d_pool_ctr = nullptr;
     h->park_min = 500; h->park_depth = 8;
-    h->excl_min = 0; h->excl_cap = 256; h->excl_yield = 0;
     h->loop_order_prev = true;
     // long instances time-share beyond this fraction of the resident waves: the favoured half of them for the one-stage kernel (two waves per SIMD),
     // 0.8 for the two-stage kernel (one wave per SIMD); measured flat between 0.4 and 0.7 / 0.5 and 1.0 (profiles/r04/sched_sweep*.txt)
@@ -1066,9 +1057,6 @@ int nmpc_new(const nmpc_problem *pb, const nmpc_opts *opts, int device_id, int m
     if (const char *env = getenv("NMPC_PARK_MIN")) h->park_min = atoi(env);       // 0 switches the slot migration off
     if (const char *env = getenv("NMPC_PARK_DEPTH")) h->park_depth = atoi(env);
     if (const char *env = getenv("NMPC_LOOP_ORDER_PREV")) h->loop_order_prev = atoi(env) != 0;
-    if (const char *env = getenv("NMPC_EXCL_MIN")) h->excl_min = atoi(env);       // 0 = no SIMD is ever held
-    if (const char *env = getenv("NMPC_EXCL_CAP")) h->excl_cap = atoi(env);
-    if (const char *env = getenv("NMPC_EXCL_YIELD")) h->excl_yield = atoi(env);
     if (const char *env = getenv("NMPC_SCHED")) h->sched_mode = atoi(env);
     if (const char *env = getenv("NMPC_SCHED_THETA")) { const double v = atof(env); if (v > 0.0) h->sched_theta = v; }
     if (const char *env = getenv("NMPC_SCHED_COLD")) { const double v = atof(env); if (v > 0.0) h->sched_cold = v; }
@@ -1138,7 +1126,7 @@ void nmpc_free(nmpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->d_queue); (void)hipFree(h->d_order); (void)hipFree(h->d_cls);
-    (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr); (void)hipFree(h->d_excl);
+    (void)hipFree(h->d_park); (void)hipFree(h->d_pool); (void)hipFree(h->d_pool_ctr);
     for (int k = 0; k < 2; ++k) { if (h->h_pin[k]) (void)hipHostFree(h->h_pin[k]); if (h->pin_ev[k]) (void)hipEventDestroy(h->pin_ev[k]); }
     (void)hipFree(h->d_small); if (h->h_small) (void)hipHostFree(h->h_small);
     for (int k = 0; k < 2; ++k) if (h->small_ev[k]) (void)hipEventDestroy(h->small_ev[k]);
@@ -1208,11 +1196,6 @@ int nmpc_solve_batch_device(nmpc_handle *h, int B, const double *d_p, double *d_
             a.park_min = h->P == 20 ? h->park_min : 0; a.park_depth = h->park_depth;      // (the slot migration is the one-stage kernel's: two waves per SIMD)
             a.park = h->d_park; a.pool = h->d_pool; a.pool_ctr = h->d_pool_ctr; a.pool_cap = (int)cap;
             a.sched_mode = h->sched_mode;
-            if (h->P == 20 && h->excl_min > 0) {
-                if (!h->d_excl) HIP_TRY(h, hipMalloc((void **)&h->d_excl, (nmpc::EXCL_KEYS + 1) * sizeof(int)));
-                HIP_TRY(h, hipMemsetAsync(h->d_excl, 0, (nmpc::EXCL_KEYS + 1) * sizeof(int), s));
-                a.excl = h->d_excl; a.excl_min = h->excl_min; a.excl_cap = h->excl_cap; a.excl_yield = h->excl_yield;
-            }
         }
     }
     {

@@ -227,25 +227,6 @@ struct FlagBit {
     __device__ __forceinline__ FlagBit &operator=(const FlagBit &o) { return *this = (bool)o; }
 };
 
-// SIMD-exclusive long instances: this wave's word of KArgs.excl (nullptr: off) and the counter of held SIMDs, read afresh from the
-// kernel-argument segment (volatile: the loads stay where they are written)
-struct ExclRef { int *word, *count; int min_passes, cap, yield; };
-__device__ __forceinline__ ExclRef excl_ref()
-{
-    typedef __attribute__((address_space(4))) const volatile char ka_bytes;
-    ka_bytes *ka = (ka_bytes *)__builtin_amdgcn_kernarg_segment_ptr();
-    ExclRef r;
-    int *base = *(int *__attribute__((address_space(4))) const volatile *)(ka + offsetof(KArgs, excl));
-    r.min_passes = *(__attribute__((address_space(4))) const volatile int *)(ka + offsetof(KArgs, excl_min));
-    r.cap = *(__attribute__((address_space(4))) const volatile int *)(ka + offsetof(KArgs, excl_cap));
-    r.yield = *(__attribute__((address_space(4))) const volatile int *)(ka + offsetof(KArgs, excl_yield));
-    const unsigned hw = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
-    const int key = (int)(((xcc & 7u) << 9) | (((hw >> 12) & 7u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u));      // XCC | SE, SH | CU | SIMD
-    r.word = base ? base + key : nullptr;
-    r.count = base ? base + EXCL_KEYS : nullptr;
-    return r;
-}
-
 template <class SH>
 __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArgs a)
 {
@@ -331,14 +312,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     // wave slot within the SIMD (HW_ID[3:0]): with two resident waves the hardware favours slot 0
     const unsigned hw_slot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 4);
     const bool unfavoured = hw_slot != 0u;
-    // SIMD-exclusive long instances.  Two waves share a SIMD, and a pass costs a wave 4.5 us then against 2.4-3.3 us alone -- but a batch ends
-    // when its longest instance does.  So an instance that has run KArgs.excl_min passes asks for its SIMD (one word per SIMD of the chip:
-    // XCC, shader engine / array, CU, SIMD from the hardware id registers; at most KArgs.excl_cap SIMDs are held at a time); while it holds
-    // it, the other wave of that SIMD starts nothing new -- it sleeps at the fetch (and as a helper) until the word is free again.  Only
-    // WHEN an instance runs changes, never its arithmetic.
-    // (Its arguments are read from the kernel-argument segment where they are used -- rare places -- so that they hold no scalar registers across
-    // the loop: every spilled scalar is reloaded through the vector ALU.)
-    const int excl_me = (int)hw_slot + 1;
     const int PS = park_stride(N);
 
     // first round: the queue's head -- the instances that look hardest -- goes to the favoured wave slots; the other
@@ -365,14 +338,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         // (favoured waves), else the queue, else -- once the queue is exhausted -- whatever is still parked
         int fetched = -1, from_pool = 0;
         if (lane == 0) {
-            {      // the other wave of this SIMD holds it (KArgs.excl): nothing new starts here meanwhile
-                const ExclRef ex_ = excl_ref();
-                while (ex_.word) {
-                    const int v_ = __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v_ == 0 || v_ == excl_me) break;
-                    __builtin_amdgcn_s_sleep(64);
-                }
-            }
             const bool pools = a.park_min > 0 || a.sched_mode > 0;
             if (pools && !unfavoured) { fetched = pool_pop(a, POOL_LONG); from_pool = fetched >= 0; }      // favoured waves: waiting long-runners first
             if (fetched < 0) {
@@ -475,7 +440,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         FlagBit running{fl, 1u << 14}, timed_out{fl, 1u << 15};
         f_start = true; running = true;
         FlagBit posted{fl, 1u << 16};                      // a request of the current iteration is open for the helpers
-        FlagBit excl_held{fl, 1u << 17};                   // this instance holds its SIMD (KArgs.excl)
 #ifdef NMPC_TL
         int tl_it = 0;                            // PANOC steps of this instance so far
 #endif
@@ -761,20 +725,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             // one the whole batch will end up waiting for.  Raise its wave's issue priority while it shares its SIMD with another
             // wave: worth 1-2 % of the headline batch (39.2 against 39.9 ms without; levels at 1k / 2k / 3k or 0.5k / 1k / 1.5k passes
             // instead of 2k / 4k / 6k: the same within noise) -- the older wave slot is still served first (top of the file).
-            if ((n_pass & 127u) == 0u && !excl_held) {
-                int got_ = 0;
-                if (lane == 0) {
-                    const ExclRef ex_ = excl_ref();
-                    if (ex_.word && n_pass >= (unsigned)ex_.min_passes && __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                        if (__hip_atomic_fetch_add(ex_.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ex_.cap) {
-                            int exp_ = 0;
-                            got_ = __hip_atomic_compare_exchange_strong(ex_.word, &exp_, excl_me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-                        }
-                        if (!got_) __hip_atomic_fetch_add(ex_.count, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                excl_held = __builtin_amdgcn_readfirstlane(got_) != 0;
-            }
             if (k_dbg == 0 && (n_pass & 1023u) == 0u) {
                 const unsigned lvl = n_pass >> 11;
                 if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
@@ -1048,14 +998,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                                     else y = (fresh_left || long_wait) && alive >= a.sched_long_cap && n_pass - q_pass >= 150u;      // (an outer iteration of a few passes is not worth a hand-over)
                                     dec = (long_now ? 2 : 0);
                                 }
-                                // the other wave of this SIMD holds it (KArgs.excl): out of its way
-                                if (!y && !excl_held) {
-                                    const ExclRef ex_ = excl_ref();
-                                    if (ex_.word && ex_.yield) {
-                                        const int v_ = __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        if (v_ != 0 && v_ != excl_me) y = 1;
-                                    }
-                                }
                                 // a long-runner on the unfavoured wave slot while favoured waves will still come back for work: hand it over
                                 if (!y && a.park_min > 0 && unfavoured && n_pass >= (unsigned)a.park_min && fresh_left && pool_depth(a, POOL_LONG) < a.park_depth) {
                                     y = 1; cls = POOL_LONG;
@@ -1079,14 +1021,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             NMPC_SEC(pf6);
         }
 
-        if (excl_held) {      // the SIMD goes back (finished or parked)
-            if (lane == 0) {
-                const ExclRef ex_ = excl_ref();
-                __hip_atomic_store(ex_.word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(ex_.count, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            excl_held = false;
-        }
         // ------------------------------------------------------------------ parked: state out, into the pool
         if (parked) {
             double *po = a.park + (size_t)inst * PS;
@@ -1171,11 +1105,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     int ws_inst = -1;
     for (;;) {
         if (!k_help || __builtin_amdgcn_readfirstlane(ctl_load(ctl + CTL_OWNERS)) <= 0) break;      // (nobody will ask: NMPC_TEAM_HELP=0)
-        // claim the next open task of some sibling's request (not on a SIMD the other wave holds: KArgs.excl)
+        // claim the next open task of some sibling's request
         int got = -1;
-        bool held_ = false;
-        if (lane == 0) { const ExclRef ex_ = excl_ref(); held_ = ex_.word && __hip_atomic_load(ex_.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
-        if (lane == 0 && !held_) {
+        if (lane == 0) {
             for (int w = 0; w < TEAM_WAVES && got < 0; ++w) {
                 if (w == wid) continue;
                 int v = ctl_load(ctl + CTL_CLAIM + w);

@@ -139,7 +139,7 @@ def rewrite(lines, name):
         nonlocal cur
         bid = len(blocks)
         assert bid < NSLOT, "more basic blocks than counters"
-        cur = {"label": label, "classes": Counter(), "n": 0, "lines": Counter()}
+        cur = {"label": label, "classes": Counter(), "ops": Counter(), "n": 0, "lines": Counter()}
         blocks.append(cur)
         if agpr_mode:
             out.extend(["\ts_mov_b64 s[100:101], exec", "\ts_mov_b64 exec, 1",
@@ -178,6 +178,7 @@ def rewrite(lines, name):
         op = t.split()[0]
         k = klass(op)
         cur["classes"][k] += 1
+        cur["ops"][re.sub(r"_(e32|e64)$", "", op)] += 1
         cur["n"] += 1
         if loc:
             cur["lines"][loc + "|" + ("valu" if k in VALU else "other")] += 1
@@ -201,6 +202,7 @@ def rewrite(lines, name):
     # (the metadata's register counts: what the loader reports, not what it allocates -- left alone)
     for b in blocks:
         b["classes"] = dict(b["classes"])
+        b["ops"] = dict(b["ops"])
         b["lines"] = dict(b["lines"])
     return text.split("\n"), blocks, va
 
@@ -288,6 +290,7 @@ def report(fn, top=40, quiet=False):
     meta = json.load(open(os.path.join(VAR, f"libnmpc_bbcount_{d['tag']}.json")))
     blocks, counts, passes = meta["blocks"], d["counts"], d["passes"]
     tot = Counter()
+    ops = Counter()
     by_line = defaultdict(lambda: [0.0, 0.0])
     rows = []
     for b, c in zip(blocks, counts):
@@ -295,6 +298,8 @@ def report(fn, top=40, quiet=False):
             continue
         for k, v in b["classes"].items():
             tot[k] += v * c
+        for k, v in b.get("ops", {}).items():
+            ops[k] += v * c
         valu = sum(v for k, v in b["classes"].items() if k in VALU)
         rows.append((valu * c, c, b))
         for key, n in b["lines"].items():
@@ -306,6 +311,7 @@ def report(fn, top=40, quiet=False):
            "passes": passes, "per_pass": per_pass, "valu_per_pass": round(valu_pp, 1),
            "f64_share_of_valu": round((tot["f64"] + tot["dpp_f64"]) / max(1, sum(v for k, v in tot.items() if k in VALU)), 3),
            "all_instructions_per_pass": round(sum(tot.values()) / passes, 1), "same_results_as_plain_build": d.get("same_results_as_plain_build")}
+    res["top_opcodes_per_pass"] = {k: round(v / passes, 2) for k, v in ops.most_common(60)}
     rows.sort(key=lambda r: -r[0])
     res["top_blocks"] = []
     for w, c, b in rows[:top]:
@@ -316,7 +322,8 @@ def report(fn, top=40, quiet=False):
     lines = sorted(by_line.items(), key=lambda kv: -kv[1][0])[:top]
     res["top_lines"] = [{"line": k, "valu_per_pass": round(v[0] / passes, 1), "other_per_pass": round(v[1] / passes, 1)} for k, v in lines]
     if not quiet:
-        print(json.dumps({k: v for k, v in res.items() if k not in ("top_blocks", "top_lines")}, indent=1))
+        print(json.dumps({k: v for k, v in res.items() if k not in ("top_blocks", "top_lines", "top_opcodes_per_pass")}, indent=1))
+        print("opcodes per pass: " + "  ".join(f"{k} {v}" for k, v in res["top_opcodes_per_pass"].items()))
         for r in res["top_blocks"]:
             print(f"{r['block']:14s} x{r['executions_per_pass']:7.3f} valu/pass {r['valu_per_pass']:7.1f}  {r['lines']:60s} " +
                   " ".join(f"{k}={v}" for k, v in sorted(r["static"].items()) if k in VALU))

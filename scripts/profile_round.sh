@@ -33,7 +33,7 @@ rocprofv3 --pmc $SQ1 -d "$OUT/pmc_team_sq" -o pmc --output-format csv -- python 
 rocprofv3 --pmc $SQ1 -d "$OUT/pmc_cfg2_sq" -o pmc --output-format csv -- python scripts/pmc_cfg2.py > "$OUT/pmc_cfg2_sq.log" 2>&1
 for c in cfg1 cfg2 cfg3 cfg4; do python scripts/win_stats.py $c $V/libnmpc_ws.so; done > "$OUT/win_stats.txt" 2>&1
 python scripts/profile_summarise.py "$OUT" > "$OUT/summarise.log" 2>&1
-cp "$OUT/traffic.json" "$OUT/scan_shares.json" "profiles/$TAG/" 2>/dev/null
+cp "$OUT/traffic.json" "$OUT/scan_shares.json" "$OUT/valu.json" "profiles/$TAG/" 2>/dev/null
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python bench.py --steps 5 --warmup 1 --no-extras > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 for c in cfg2 cfg3 cfg4; do
     rocprofv3 --kernel-trace --stats -d "$OUT/trace_$c" -o trace --output-format csv -- python bench.py --config $c --steps 3 --warmup 1 --no-extras > "$OUT/bench_${c}_under_rocprof.json" 2> "$OUT/trace_$c.log"

@@ -60,6 +60,31 @@ for k in fetch:
 with open(os.path.join(out, "traffic.json"), "w") as fh:
     json.dump(entries, fh, indent=1)
 print(json.dumps(entries))
+# valu.json: instructions per evaluation pass and how busy the vector ALU is, from the SQ counter pass of the same batch (pmc_sq) and of the cfg 2
+# batch (pmc_cfg2_sq), keyed like the traffic -- bench.py quotes roofline.valu_per_pass / roofline.valu_busy from it
+valu = []
+for name, cfgname, waves_per_simd in (("sq", "cfg1", 2), ("cfg2_sq", "cfg2", 1)):
+    log = os.path.join(out, f"pmc_{name}.log")
+    passes = None
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("launches"):
+                w_ = line.split()
+                passes = float(w_[w_.index("passes/launch") + 1])
+    for k in sorted({k for (n, k, c) in per_kernel if n == name and "solve" in k}):
+        g = lambda c: per_kernel.get((name, k, c))      # noqa: E731
+        if passes and g("SQ_INSTS_VALU") and g("SQ_WAVE_CYCLES"):
+            short = k.split("(")[0].replace("void ", "").replace("nmpc::", "").replace("<nmpc::", "<").strip()
+            valu.append({"kernel": short, "source_hash": _lib.source_hash(), "config": cfgname, "batch": 8192, "passes_per_launch": passes,
+                         "valu_per_pass": g("SQ_INSTS_VALU") / passes, "salu_per_pass": (g("SQ_INSTS_SALU") or 0.0) / passes,
+                         "lds_per_pass": (g("SQ_INSTS_LDS") or 0.0) / passes,
+                         "valu_busy_per_wave": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"), "waves_per_simd": waves_per_simd,
+                         "valu_busy": waves_per_simd * g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
+                         "how": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES (one run, no trace domains) of two launches of "
+                                "the batch; per launch / evaluation passes of the launch (sum of nmpc_status.reserved); valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves per SIMD"})
+with open(os.path.join(out, "valu.json"), "w") as fh:
+    json.dump(valu, fh, indent=1)
+print(json.dumps(valu))
 # scan_shares.json: share of the evaluations in which the exact certificates of eval_psi fell back (scripts/win_stats.py on a -DNMPC_WIN_STATS
 # build), keyed like the traffic -- bench.py derives roofline.executed_frac from it
 ws = os.path.join(out, "win_stats.txt")

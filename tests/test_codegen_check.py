@@ -48,3 +48,25 @@ def test_exec_restore_check_flags_vector_copies_in_front_of_the_restore():
     fixed = "\n".join(rest[:k + 1] + copies + rest[k + 1:])
     nfun, nrestore, hits = cc.check_exec_restores(fixed)
     assert nrestore == 1 and not hits
+
+
+def test_dpp_hazard_check_counts_wait_states():
+    """check 3: a DPP read needs two wait states after a vector write of its source; s_nop N gives N + 1, any instruction gives one."""
+    asm = """_Z3foov:
+\tv_add_f64 v[6:7], v[6:7], v[2:3]
+\ts_mov_b32 exec_hi, s0
+\tv_mov_b32_dpp v2, v6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+\tv_add_f64 v[8:9], v[6:7], v[2:3]
+\ts_nop 1
+\tv_mov_b32_dpp v2, v9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+\tv_add_f64 v[8:9], v[6:7], v[2:3]
+\ts_nop 0
+\tv_fmac_f64_dpp v[10:11], v[8:9], v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf
+\tv_add_f64 v[8:9], v[6:7], v[2:3]
+\ts_mov_b32 exec_hi, s0
+\ts_nop 0
+\tv_mov_b32_dpp v2, v8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+.Lfunc_end0:
+"""
+    n, bad = cc.check_dpp_hazards(asm)
+    assert n == 4 and [b[1].split()[0] for b in bad] == ["v_mov_b32_dpp", "v_fmac_f64_dpp"] and "v6" in bad[0][1]
