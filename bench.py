@@ -76,7 +76,7 @@ WORKLOADS = {   # what each BASELINE.json configuration is made of (mpc_trajecto
     "cfg3": "configs/default.yaml with Nobs overridden to 50, all slots filled from a synthetic random-polygon circle field",
     "cfg4": "configs/smooth_velocity.yaml's weights/bounds overlaid on default.yaml (N_hor=20), three random moving ellipses per instance",
 }
-POINTS_PER_PASS = {"nmpc_solve_hyb_kernel": 3, "nmpc_solve_hyb2_kernel": 3, "nmpc_solve_kernel": 1}
+POINTS_PER_PASS = {"nmpc_solve_hyb_kernel": 3, "nmpc_solve_hyb2_kernel": 3}
 
 
 def flop_model(cfg):
@@ -379,6 +379,10 @@ def main():
                      + s["num_inner_iterations"].astype(np.float64).sum() * f_iter)
 
     flops = flops_of(st)
+    # SURVEY.md section 8(d)'s literal formula beside it: n_cost F_cost + n_grad 4 F_cost + iterations 46 n_u (its "reverse mode = 3 x forward" guess
+    # for the adjoint; the as-implemented adjoint above is far cheaper, so this figure is the larger one)
+    flops_survey = float(st["num_cost_evals"].astype(np.float64).sum() * f_fwd + st["num_grad_evals"].astype(np.float64).sum() * 4.0 * f_fwd
+                         + st["num_inner_iterations"].astype(np.float64).sum() * 46.0 * cfg.n_u)
     # what the ALUs execute of that: the windowed cross-track search measures three segments instead of N - 1, the obstacle certificate
     # skips the activity scan -- both exact, both fall back to the full work in a measured share of the evaluations
     shares, shares_src = scan_shares(solver.kernel_name, args.config)
@@ -389,6 +393,11 @@ def main():
         f_fwd_x = N_ * (28 + (7 * No_ + 15 * Nd_) * so + 21 * ((N_ - 1) * sw + 3 * (1 - sw))) + 14 * N_
         n_ev = float(st["num_cost_evals"].astype(np.float64).sum() + st["num_grad_evals"].astype(np.float64).sum())
         executed_frac = (flops - n_ev * (f_fwd - f_fwd_x)) / flops
+    else:
+        print(f"bench.py: no certificate shares for these kernel sources under profiles/*/scan_shares.json -- roofline.executed_frac is null "
+              f"(scripts/win_stats.py {args.config} measures them)", file=sys.stderr)
+    valu_pmc, valu_src = pmc_valu(solver.kernel_name, args.config)
+    mix, mix_src = dynamic_mix(solver.kernel_name, args.config)
     bytes_alg = float(B * (8 * (cfg.n_p + 2 * cfg.n_u + cfg.n1) + 72))
     conv = st["exit_status"] == 0
     stats = np.array([st["num_inner_iterations"].sum(), st["num_outer_iterations"].sum(), conv.sum(), B,
@@ -526,22 +535,31 @@ def main():
                               "points_per_pass": POINTS_PER_PASS.get(solver.kernel_name.split("<")[0]),
                               "slowest_instance_ms": float(st["solve_time_ms"].max()),
                               "mean_instance_ms": float(st["solve_time_ms"].mean())},
-        # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s);
-        # the kernel issues no MFMA -- "bound_detail" says what actually limits it
-        "roofline": {"bound": "valu_f64", "bound_class": "mfma (the compute-side roofline of the bench contract; the kernel issues no MFMA)",
+        # compute-bound, priced against the dense f64 peak (MI355X: vector f64 = f64 MFMA = 78.6 TFLOP/s).  `bound` stays inside the bench contract's
+        # enum -- "mfma" is its compute-side roofline --, `bound_class` says which unit it is: the f64 vector ALU (the kernel issues no MFMA)
+        "roofline": {"bound": "mfma", "bound_class": "valu_f64",
                      "model": "algorithmic flops of the sequential method from the solver's own counters: F_fwd = N(28 + 7 Nobs + 15 Ndyn + 21 (N - 1)) + 14 N "
                               "per evaluation (SURVEY.md App. G), + the as-implemented adjoint N(88 + 9 Nobs + 16 Ndyn) per gradient (NOT the survey's 4 x F_cost guess), "
                               "+ 70 n_u per PANOC iteration; fma = 2",
+                     "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
+                     # the same launch by SURVEY.md section 8(d)'s literal formula (cost + gradient = 4 F_cost, 46 n_u per iteration)
+                     "frac_survey_model": flops_survey / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS, "flops_per_launch_survey_model": flops_survey,
                      "executed_frac": executed_frac, "executed_frac_source": shares_src,
                      "executed_frac_note": "share of the credited flops the ALUs execute: the exact windowed cross-track search and the exact obstacle "
                                            "certificate skip the rest (null: certificates not counted for these sources)",
-                     "achieved": flops / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F64_VALU_TFLOPS,
-                     "unit": "TFLOP/s", "frac": flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
+                     # what the ALUs execute of the credited flops, per second and against the peak
+                     "achieved_executed": None if executed_frac is None else executed_frac * flops / (kern_ms * 1e-3) / 1e12,
+                     "frac_executed": None if executed_frac is None else executed_frac * flops / (kern_ms * 1e-3) / 1e12 / PEAK_F64_VALU_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)", "traffic_source": traffic_src,
+                     # vector instructions per evaluation pass and the vector ALU's busy share (rocprofv3 SQ counters), executed instructions per pass by
+                     # class (basic-block counters, scripts/bbcount.py): all keyed by the hash of the kernel sources, null when measured for other sources
+                     "valu_per_pass": None if not valu_pmc else valu_pmc["valu_per_pass"], "valu_busy": None if not valu_pmc else valu_pmc["valu_busy"],
+                     "valu_source": valu_src, "dynamic_mix": mix, "dynamic_mix_source": mix_src,
                      "kernel": solver.kernel_name, "kernel_ms": kern_ms,
                      "flops_per_launch": flops,
-                     "note": "f64 vector-ALU issue bounds this kernel, not HBM or MFMA (SURVEY.md section 8d); "
-                             "MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},
+                     "note": "instruction issue bounds this kernel -- a wave issues one instruction of any class per slot, 60 % of them vector-ALU, half of "
+                             "those f64 arithmetic --, not HBM or MFMA (SURVEY.md section 8d; DESIGN.md section 5.6); MI355X f64 MFMA dense peak is the same 78.6 TFLOP/s"},
         "roofline_hbm": {"bound": "hbm", "achieved": bytes_alg / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": bytes_alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                          "traffic": traffic, "bytes_per_launch": bytes_alg, "traffic_source": traffic_src},

@@ -147,40 +147,60 @@ def variant_path(name: str) -> str:
     return os.path.join(_CSRC, "variants", f"libnmpc_{name}.so")
 
 
+def _variant_key() -> str:
+    """What a variant is fresh for: the kernel sources AND the Makefile (a flag change rebuilds the variants too)."""
+    import hashlib
+    with open(os.path.join(_CSRC, "Makefile"), "rb") as fh:
+        return source_hash() + "+" + hashlib.sha256(fh.read()).hexdigest()[:8]
+
+
 def build_variant(name: str, force: bool = False) -> dict:
-    """Build csrc/variants/libnmpc_<name>.so with strategy `name` and run the code-generation check on it; -> that check's result."""
+    """Build csrc/variants/libnmpc_<name>.so with strategy `name` and run the code-generation check on ITS flags (the experiments variant:
+    the shipped flags + -DNMPC_EXPERIMENTS); -> that check's result.  A variant whose check fails is not put in place."""
     from . import codegen_check
     import fcntl
     experiments = name == EXPERIMENTS
     flags = None if experiments else STRATEGIES[name]
     out, meta = variant_path(name), variant_path(name)[:-3] + ".json"
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    if os.path.exists(out) and os.path.exists(meta) and not force:      # fresh = built from these very sources (content, not time stamps)
-        with open(meta) as fh:
-            res = json.load(fh)
-        if res.get("source_hash") == source_hash():
-            return res
+
+    def fresh():
+        if os.path.exists(out) and os.path.exists(meta) and not force:      # fresh = built from these very sources (content, not time stamps)
+            try:
+                with open(meta) as fh:
+                    res = json.load(fh)
+            except (OSError, ValueError):
+                return None
+            if res.get("variant_key") == _variant_key():
+                return res
+        return None
+
+    res = fresh()
+    if res is not None:
+        return res
     with open(os.path.join(_CSRC, ".build.lock"), "w") as lock:      # (several test processes may ask for the same variant)
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if os.path.exists(out) and os.path.exists(meta) and not force:
-                with open(meta) as fh:
-                    res = json.load(fh)
-                if res.get("source_hash") == source_hash():
-                    return res
+            res = fresh()
+            if res is not None:
+                return res
             tmp = os.path.relpath(out, _CSRC) + f".tmp{os.getpid()}"
             cmd = ["make", "-C", _CSRC, "-B", tmp, f"OUT={tmp}"] + (["EXTRA=-DNMPC_EXPERIMENTS"] if experiments else ["SCHED=" + " ".join(flags)])
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"building {out} failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
+            res = codegen_check.verify(codegen_check.makefile_flags() + ["-DNMPC_EXPERIMENTS"]) if experiments else codegen_check.verify(flags)
+            res.pop("resources", None)
+            res["source_hash"] = source_hash()
+            res["variant_key"] = _variant_key()
+            if experiments and not res["ok"]:      # (the strategy variants are kept even when the check objects: tests/test_gpu_strategies.py reports on them)
+                os.remove(os.path.join(_CSRC, tmp))
+                raise RuntimeError(f"{out} REFUSED by the code-generation check: " + json.dumps({k: v for k, v in res.items() if k != "details"})[:2000])
             os.replace(os.path.join(_CSRC, tmp), out)
+            with open(meta, "w") as fh:      # (under the lock: library and verdict change together)
+                json.dump(res, fh)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    res = codegen_check.verify(flags) if not experiments else dict(build_info().get("codegen_check", {"ok": True}))      # (experiments: the shipped kernels' machine code)
-    res.pop("resources", None)
-    res["source_hash"] = source_hash()
-    with open(meta, "w") as fh:
-        json.dump(res, fh)
     return res
 
 

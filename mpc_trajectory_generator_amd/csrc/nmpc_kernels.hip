@@ -1332,7 +1332,10 @@ static int solve_small_host(nmpc_handle *h, int B, const double *p, double *u, c
                  o_st = o_yo + cap * n1 * 8, total = o_st + cap * sizeof(nmpc_status);
     HIP_TRY(h, hipSetDevice(h->device));
     if (!h->small_ready) {
-        if (h->d_small) return fail(h, NMPC_ERR_HIP, "small-batch arena: an earlier allocation failed half way");
+        // all or none: what an earlier, failed attempt left behind is released first, so a transient failure costs one call, not the handle's small-batch path
+        (void)hipFree(h->d_small); h->d_small = nullptr;
+        if (h->h_small) { (void)hipHostFree(h->h_small); h->h_small = nullptr; }
+        for (int k = 0; k < 2; ++k) if (h->small_ev[k]) { (void)hipEventDestroy(h->small_ev[k]); h->small_ev[k] = nullptr; }
         HIP_TRY(h, hipMalloc((void **)&h->d_small, total));
         HIP_TRY(h, hipHostMalloc((void **)&h->h_small, total, hipHostMallocDefault));
         for (int k = 0; k < 2; ++k) HIP_TRY(h, hipEventCreate(&h->small_ev[k]));

@@ -195,25 +195,39 @@ __device__ __forceinline__ double lane_scalar(double v, int ln)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ln);
     return __hiloint2double(hi, lo);
 }
-// one step of the first / second recurrence (J = age of the pair) with the direction's update of that step
-#define NMPC_GRAM_FWD(J)                                                                       \
+// one step of the first / second recurrence (J = age of the pair, H = the ring's head) with the direction's update of that step.  The pair of
+// age J sits in ring slot (H + J) mod 10: with H a compile-time constant every LDS address of a step is a per-lane base plus an immediate --
+// so the twenty steps exist once per head position (a ten-way switch on the wave-uniform head), 3 scalar and 2 vector address instructions
+// per step less than with the head in a register: the kernel is bound by instruction issue of ANY class.
+#define NMPC_GRAM_FWD(H, J)                                                                    \
     do {                                                                                       \
-        const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J);        \
+        constexpr int pj_ = ((H) + (J)) % MAXMEM;                                              \
         const double gs_ = Lgsy[pkrow + pj_], gy_ = Lgyy[pkrow + pj_];                         \
         const dbl2 yp_ = LY[pj_ * NS + tt];                                                    \
         const double al_ = rho_k * ga1;                                                        \
         ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                                              \
         fnma3_row_bcast<(J)>(ga2, dv, dw, al_, gy_, yp_.x, yp_.y, ga1);                        \
     } while (0)
-#define NMPC_GRAM_BWD(J)                                                                       \
+#define NMPC_GRAM_BWD(H, J)                                                                    \
     do {                                                                                       \
-        const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J);        \
+        constexpr int pj_ = ((H) + (J)) % MAXMEM;                                              \
         const double gr_ = Lgsy[pj_ * GRAM_LD + pk_];                                           \
         const dbl2 sp_ = LS[pj_ * NS + tt];                                                    \
         const double be_ = rho_k * ga2;                                                        \
         const double ab_ = alv - be_;                                                          \
         ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                                               \
         fma2_row_bcast<(J)>(dv, dw, ab_, sp_.x, sp_.y, ga2);                                   \
+    } while (0)
+// both recurrences for the head position H
+#define NMPC_GRAM_BOTH(H)                                                                                                            \
+    do {                                                                                                                             \
+        NMPC_GRAM_FWD(H, 0); NMPC_GRAM_FWD(H, 1); NMPC_GRAM_FWD(H, 2); NMPC_GRAM_FWD(H, 3); NMPC_GRAM_FWD(H, 4);                     \
+        NMPC_GRAM_FWD(H, 5); NMPC_GRAM_FWD(H, 6); NMPC_GRAM_FWD(H, 7); NMPC_GRAM_FWD(H, 8); NMPC_GRAM_FWD(H, 9);                     \
+        const double alv = rho_k * ga1;          /* alpha_k in lane k: entry k of ga1 is final once step k has used it */              \
+        ga2 = n_H0 * ga2;                                                                                                            \
+        dv = n_H0 * dv; dw = n_H0 * dw;                                                                                              \
+        NMPC_GRAM_BWD(H, 9); NMPC_GRAM_BWD(H, 8); NMPC_GRAM_BWD(H, 7); NMPC_GRAM_BWD(H, 6); NMPC_GRAM_BWD(H, 5);                     \
+        NMPC_GRAM_BWD(H, 4); NMPC_GRAM_BWD(H, 3); NMPC_GRAM_BWD(H, 2); NMPC_GRAM_BWD(H, 1); NMPC_GRAM_BWD(H, 0);                     \
     } while (0)
 
 // The state machine's wave-uniform flags are bits of ONE 32-bit scalar.  As `bool`s each is a 64-bit lane mask (two scalar registers,
@@ -647,13 +661,18 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                         double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
                         if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }      // (the ring held the evicted pair)
                         const double rho_k = Lrho[pk_];
-                        NMPC_GRAM_FWD(0); NMPC_GRAM_FWD(1); NMPC_GRAM_FWD(2); NMPC_GRAM_FWD(3); NMPC_GRAM_FWD(4);
-                        NMPC_GRAM_FWD(5); NMPC_GRAM_FWD(6); NMPC_GRAM_FWD(7); NMPC_GRAM_FWD(8); NMPC_GRAM_FWD(9);
-                        const double alv = rho_k * ga1;          // alpha_k in lane k: entry k of ga1 is final once step k has used it
-                        ga2 = n_H0 * ga2;
-                        dv = n_H0 * dv; dw = n_H0 * dw;
-                        NMPC_GRAM_BWD(9); NMPC_GRAM_BWD(8); NMPC_GRAM_BWD(7); NMPC_GRAM_BWD(6); NMPC_GRAM_BWD(5);
-                        NMPC_GRAM_BWD(4); NMPC_GRAM_BWD(3); NMPC_GRAM_BWD(2); NMPC_GRAM_BWD(1); NMPC_GRAM_BWD(0);
+                        switch (n_head) {
+                        case 0: NMPC_GRAM_BOTH(0); break;
+                        case 1: NMPC_GRAM_BOTH(1); break;
+                        case 2: NMPC_GRAM_BOTH(2); break;
+                        case 3: NMPC_GRAM_BOTH(3); break;
+                        case 4: NMPC_GRAM_BOTH(4); break;
+                        case 5: NMPC_GRAM_BOTH(5); break;
+                        case 6: NMPC_GRAM_BOTH(6); break;
+                        case 7: NMPC_GRAM_BOTH(7); break;
+                        case 8: NMPC_GRAM_BOTH(8); break;
+                        default: NMPC_GRAM_BOTH(9); break;
+                        }
                     }
 #ifdef NMPC_PROF2
                     { double keep = dv + dw; asm volatile("" : "+v"(keep)); }
@@ -1197,6 +1216,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #undef NMPC_LB_ZERO
 #undef NMPC_GRAM_FWD
 #undef NMPC_GRAM_BWD
+#undef NMPC_GRAM_BOTH
 #undef NMPC_TAKE_TRIAL
 #undef NMPC_HALF_STEP
 #undef NMPC_FBE

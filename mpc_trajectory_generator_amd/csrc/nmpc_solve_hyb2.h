@@ -1,4 +1,4 @@
-// nmpc_solve_hyb2.h -- the 32 < N_hor <= 40 solver (BASELINE config 2: N_hor = 40): the design of nmpc_solve_hyb.h with
+// nmpc_solve_hyb2.h -- the 20 < N_hor <= 40 solver (BASELINE config 2: N_hor = 40): the design of nmpc_solve_hyb.h with
 // TWO STAGES PER LANE.
 //
 // One problem instance per wavefront, THREE query points per pass: the evaluation runs in the "tri" lane layout of
@@ -541,7 +541,7 @@ __device__ __forceinline__ void eval_psi2(const KArgs &a, lds_double *L, const L
 }
 
 // ---------------------------------------------------------------------------------------------
-// cost-layer kernel for 32 < N_hor <= 40: three instances per wave (one per lane group), the pair-form arithmetic
+// cost-layer kernel for 20 < N_hor <= 40: three instances per wave (one per lane group), the pair-form arithmetic
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void nmpc_eval2_kernel(KArgs a)
 {
@@ -908,9 +908,10 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
                         if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }
                         const double rho_k = Lrho[pk_];
-#define NMPC2_GRAM_FWD(J)                                                                          \
+// (nmpc_solve_hyb.h: the twenty steps once per head position H of the ring -- every LDS address a per-lane base plus an immediate)
+#define NMPC2_GRAM_FWD(H, J)                                                                       \
                         do {                                                                       \
-                            const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J); \
+                            constexpr int pj_ = ((H) + (J)) % MAXMEM;                              \
                             const double gs_ = Lgsy[pkrow + pj_], gy_ = Lgyy[pkrow + pj_];         \
                             D2 y1_, y2_;                                                           \
                             ld4<H2_NS>(LY + 2 * H2_NS * (pj_), tt, y1_, y2_);                      \
@@ -918,9 +919,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                              \
                             fnma5_row_bcast<(J)>(ga2, dv.a, dv.b, dw.a, dw.b, al_, gy_, y1_.a, y1_.b, y2_.a, y2_.b, ga1); \
                         } while (0)
-#define NMPC2_GRAM_BWD(J)                                                                          \
+#define NMPC2_GRAM_BWD(H, J)                                                                       \
                         do {                                                                       \
-                            const int pj_ = n_head + (J) >= MAXMEM ? n_head + (J) - MAXMEM : n_head + (J); \
+                            constexpr int pj_ = ((H) + (J)) % MAXMEM;                              \
                             const double gr_ = Lgsy[pj_ * GRAM_LD + pk_];                           \
                             D2 s1_, s2_;                                                           \
                             ld4<H2_NS>(LS + 2 * H2_NS * (pj_), tt, s1_, s2_);                      \
@@ -929,15 +930,31 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                             ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                               \
                             fma4_row_bcast<(J)>(dv.a, dv.b, dw.a, dw.b, ab_, s1_.a, s1_.b, s2_.a, s2_.b, ga2); \
                         } while (0)
-                        NMPC2_GRAM_FWD(0); NMPC2_GRAM_FWD(1); NMPC2_GRAM_FWD(2); NMPC2_GRAM_FWD(3); NMPC2_GRAM_FWD(4);
-                        NMPC2_GRAM_FWD(5); NMPC2_GRAM_FWD(6); NMPC2_GRAM_FWD(7); NMPC2_GRAM_FWD(8); NMPC2_GRAM_FWD(9);
-                        const double alv = rho_k * ga1;
-                        ga2 = n_H0 * ga2;
-                        dv = n_H0 * dv; dw = n_H0 * dw;
-                        NMPC2_GRAM_BWD(9); NMPC2_GRAM_BWD(8); NMPC2_GRAM_BWD(7); NMPC2_GRAM_BWD(6); NMPC2_GRAM_BWD(5);
-                        NMPC2_GRAM_BWD(4); NMPC2_GRAM_BWD(3); NMPC2_GRAM_BWD(2); NMPC2_GRAM_BWD(1); NMPC2_GRAM_BWD(0);
+#define NMPC2_GRAM_BOTH(H)                                                                                                                \
+                        do {                                                                                                              \
+                            NMPC2_GRAM_FWD(H, 0); NMPC2_GRAM_FWD(H, 1); NMPC2_GRAM_FWD(H, 2); NMPC2_GRAM_FWD(H, 3); NMPC2_GRAM_FWD(H, 4);  \
+                            NMPC2_GRAM_FWD(H, 5); NMPC2_GRAM_FWD(H, 6); NMPC2_GRAM_FWD(H, 7); NMPC2_GRAM_FWD(H, 8); NMPC2_GRAM_FWD(H, 9);  \
+                            const double alv = rho_k * ga1;                                                                               \
+                            ga2 = n_H0 * ga2;                                                                                             \
+                            dv = n_H0 * dv; dw = n_H0 * dw;                                                                               \
+                            NMPC2_GRAM_BWD(H, 9); NMPC2_GRAM_BWD(H, 8); NMPC2_GRAM_BWD(H, 7); NMPC2_GRAM_BWD(H, 6); NMPC2_GRAM_BWD(H, 5);  \
+                            NMPC2_GRAM_BWD(H, 4); NMPC2_GRAM_BWD(H, 3); NMPC2_GRAM_BWD(H, 2); NMPC2_GRAM_BWD(H, 1); NMPC2_GRAM_BWD(H, 0);  \
+                        } while (0)
+                        switch (n_head) {
+                        case 0: NMPC2_GRAM_BOTH(0); break;
+                        case 1: NMPC2_GRAM_BOTH(1); break;
+                        case 2: NMPC2_GRAM_BOTH(2); break;
+                        case 3: NMPC2_GRAM_BOTH(3); break;
+                        case 4: NMPC2_GRAM_BOTH(4); break;
+                        case 5: NMPC2_GRAM_BOTH(5); break;
+                        case 6: NMPC2_GRAM_BOTH(6); break;
+                        case 7: NMPC2_GRAM_BOTH(7); break;
+                        case 8: NMPC2_GRAM_BOTH(8); break;
+                        default: NMPC2_GRAM_BOTH(9); break;
+                        }
 #undef NMPC2_GRAM_FWD
 #undef NMPC2_GRAM_BWD
+#undef NMPC2_GRAM_BOTH
                     }
                     if (!fbe_ok) { fbe_u = NMPC2_FBE(uv, uw); fbe_ok = true; }
                     rhs_ls = fbe_u - sigma * nr2;

@@ -14,6 +14,7 @@ the counters; `report` multiplies the two.
   python scripts/bbcount.py build [hyb|hyb2] [tag]                 (CPU: cross-compiles)
   python scripts/bbcount.py run <tag> <cfg> [B] [instance]         (GPU)  -> gpurun_out/bbcount_<tag>_<cfg>[_i<instance>].json
   python scripts/bbcount.py report <counts.json> [top]             (CPU)
+  python scripts/bbcount.py collect <out.json> <counts.json> ...   (CPU)  -> profiles/<round>/dynamic_mix.json (bench.py quotes it by source hash)
 """
 import json
 import os
@@ -248,6 +249,9 @@ def gpu_run(tag, cfgname, B, inst):
     import ctypes as C
     import numpy as np
     lib_path = os.path.join(VAR, f"libnmpc_bbcount_{tag}.so")
+    from mpc_trajectory_generator_amd import _lib as _l
+    if not os.path.exists(lib_path) or json.load(open(lib_path[:-3] + ".json")).get("source_hash") != _l.source_hash():
+        build(json.load(open(lib_path[:-3] + ".json"))["which"] if os.path.exists(lib_path[:-3] + ".json") else tag, tag)      # (built for other sources)
     os.environ["NMPC_LIB_PATH"] = lib_path
     from mpc_trajectory_generator_amd import named_config, _lib
     from mpc_trajectory_generator_amd.solver import BatchSolver
@@ -340,5 +344,16 @@ if __name__ == "__main__":
         build(which, sys.argv[3] if len(sys.argv) > 3 else which)
     elif cmd == "run":
         gpu_run(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 8192, int(sys.argv[5]) if len(sys.argv) > 5 else None)
+    elif cmd == "collect":      # collect <out.json> <counts.json> ...: the reports of several runs as one list (profiles/<round>/dynamic_mix.json)
+        rows = []
+        for fn in sys.argv[3:]:
+            r = report(fn, 16, quiet=True)
+            r["top_lines"] = r["top_lines"][:16]
+            r["how"] = ("scripts/bbcount.py: executions of every basic block counted on the GPU (four instructions at the head of each block of the "
+                        "compiler's own assembly, registers the kernel does not use; results checked against the plain build) x the block's static classes; "
+                        "per evaluation pass = / sum of nmpc_status.reserved")
+            rows.append(r)
+        json.dump(rows, open(sys.argv[2], "w"), indent=1)
+        print(sys.argv[2], len(rows), "entries")
     elif cmd == "report":
         report(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40)

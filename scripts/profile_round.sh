@@ -2,8 +2,9 @@
 # Collects the evidence behind bench.py's numbers on the GPU box (one gpurun call; everything lands under gpurun_out/prof_<tag>/):
 #   1. PMC passes, each in its own run (no trace domains): FETCH_SIZE | WRITE_SIZE | SQ instruction mix | SQ waits, for the headline batch,
 #      for ONE hard instance solved alone (with and without helpers) and for the cfg 2 batch          -> pmc_*.csv, traffic.json
+#   1b. executed instructions per evaluation pass by class: basic-block counters in the compiler's own assembly (scripts/bbcount.py)   -> dynamic_mix.json
 #   2. how often the exact certificates of eval_psi fall back (a -DNMPC_WIN_STATS build)               -> scan_shares.json
-#      (traffic.json and scan_shares.json are copied into profiles/<tag>/ ON THE BOX before the bench lines: bench.py quotes them by source hash)
+#      (traffic.json, valu.json, dynamic_mix.json and scan_shares.json are copied into profiles/<tag>/ ON THE BOX before the bench lines: bench.py quotes them by source hash)
 #   3. rocprofv3 kernel trace + stats of the bench's timed steps, all four configurations             -> kernel_stats*.csv (must agree with kernel_ms)
 #   4. the bench lines: headline (the driver's command line), the other BASELINE configs, budget, RCCL at world size 1, the closed loop
 #   5. probes: seeds, small-batch latency, call latency, scheduler on / off, utilisation, scrub, cycles by section, timeline of a helped iteration
@@ -31,6 +32,10 @@ for pass in "lone_sq:$SQ1" "lone_wait:$SQ2"; do      # ONE wave on the chip: hel
 done
 rocprofv3 --pmc $SQ1 -d "$OUT/pmc_team_sq" -o pmc --output-format csv -- python scripts/pmc_lone.py > "$OUT/pmc_team_sq.log" 2>&1      # the same instance with its three helpers
 rocprofv3 --pmc $SQ1 -d "$OUT/pmc_cfg2_sq" -o pmc --output-format csv -- python scripts/pmc_cfg2.py > "$OUT/pmc_cfg2_sq.log" 2>&1
+# (scripts/bbcount.py run rebuilds its library when it was made from other sources)
+{ timeout 600 python scripts/bbcount.py run hyb cfg1 8192; timeout 300 python scripts/bbcount.py run hyb cfg1 1 929; timeout 600 python scripts/bbcount.py run hyb cfg4 8192; } > "$OUT/bbcount.log" 2>&1
+python scripts/bbcount.py collect "$OUT/dynamic_mix.json" gpurun_out/bbcount_hyb_cfg1.json gpurun_out/bbcount_hyb_cfg1_i929.json gpurun_out/bbcount_hyb_cfg4.json >> "$OUT/bbcount.log" 2>&1
+cp "$OUT/dynamic_mix.json" "profiles/$TAG/" 2>/dev/null
 for c in cfg1 cfg2 cfg3 cfg4; do python scripts/win_stats.py $c $V/libnmpc_ws.so; done > "$OUT/win_stats.txt" 2>&1
 python scripts/profile_summarise.py "$OUT" > "$OUT/summarise.log" 2>&1
 cp "$OUT/traffic.json" "$OUT/scan_shares.json" "$OUT/valu.json" "profiles/$TAG/" 2>/dev/null
