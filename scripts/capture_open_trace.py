@@ -22,6 +22,10 @@ The output is data only (arrays + a few strings).  tests/test_open_trace.py cons
 under every combination of the restatement switches (include/nmpc_solver.h: akkt_gradient, ls_failure,
 inner_status; tcp_shim: keep_multipliers) and reports which combination reproduces OpEn's iteration counts, exit
 statuses and solutions -- that combination then becomes the default, and the kernels follow bit for bit.
+Defaults in force (nmpc_default_opts / orc_default_opts): akkt_gradient = 1, ls_failure = 0, inner_status = 0, max_total_inner = 0;
+akkt_gradient is the switch to settle first (the headline's mean iteration count hangs on it by a factor of fifteen).  Round-off level
+choices of the restatement (Gram-form L-BFGS, ||r|| < eps gamma for the AKKT residual, the envelope's 0.5 / gamma
+factor, the C-BFGS test without its division) are not switches: a trace agrees with them to solver tolerance, not bit for bit.
 """
 import argparse
 import glob

@@ -11,4 +11,4 @@ P = synthetic_batch(cfg, 11, 8192, 0, routes=random_routes(cfg, 11, 32, seed=100
 for _ in range(2):
     u, y, st = sol.solve(P)
 ev = (st["num_cost_evals"].astype(np.int64) + st["num_grad_evals"]).sum()
-print("launches 2 evals/launch", int(ev), "iters", int(st["num_inner_iterations"].astype(np.int64).sum()), "ms", sol.last_batch_ms)
+print("launches 2 passes/launch", int(st["reserved"].astype(np.int64).sum()), "evals/launch", int(ev), "iters", int(st["num_inner_iterations"].astype(np.int64).sum()), "ms", sol.last_batch_ms)

@@ -70,7 +70,8 @@ for name, cfgname, waves_per_simd in (("sq", "cfg1", 2), ("cfg2_sq", "cfg2", 1))
         for line in open(log):
             if line.startswith("launches"):
                 w_ = line.split()
-                passes = float(w_[w_.index("passes/launch") + 1])
+                if "passes/launch" in w_:
+                    passes = float(w_[w_.index("passes/launch") + 1])
     for k in sorted({k for (n, k, c) in per_kernel if n == name and "solve" in k}):
         g = lambda c: per_kernel.get((name, k, c))      # noqa: E731
         if passes and g("SQ_INSTS_VALU") and g("SQ_WAVE_CYCLES"):
