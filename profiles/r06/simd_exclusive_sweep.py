@@ -1,6 +1,6 @@
 """A/B of the SIMD-exclusive long instances (KArgs.excl, nmpc_solve_hyb.h) on one box: kernel ms of a config's batch for a grid of
 (NMPC_EXCL_MIN, NMPC_EXCL_CAP, NMPC_EXCL_YIELD) settings of the experiments build, same checksum demanded in every row.
-usage: python scripts/excl_sweep.py cfg1 "0" "2000,256,0" "3000,128,1" ..."""
+usage: python profiles/r06/simd_exclusive_sweep.py (with profiles/r06/simd_exclusive.patch applied) cfg1 "0" "2000,256,0" "3000,128,1" ..."""
 import json
 import os
 import sys
