@@ -141,6 +141,9 @@ STRATEGIES = {"default": [], "max-memory-clause": ["-mllvm", "-amdgpu-sched-stra
 # The shipped library reads no environment variable.  The knobs tests and scripts need (force the run-time-shape kernel, team modes, scheduler
 # and migration settings, culling radius) exist only in this variant: the shipped sources and scheduler flags + -DNMPC_EXPERIMENTS.
 EXPERIMENTS = "experiments"
+# Documented compile-time settings of the kernels, each with the shipped scheduler flags: tests demand the shipped library's bits from them.
+# win0: -DNMPC_WIN=0 -DNMPC_WIN2=0 (both solve kernels), the cross-track search always as the full scan (the obstacle certificate and its helper-side guard stay on).
+DEFINES = {"win0": ["-DNMPC_WIN=0", "-DNMPC_WIN2=0"]}
 
 
 def variant_path(name: str) -> str:
@@ -160,7 +163,8 @@ def build_variant(name: str, force: bool = False) -> dict:
     from . import codegen_check
     import fcntl
     experiments = name == EXPERIMENTS
-    flags = None if experiments else STRATEGIES[name]
+    defines = DEFINES.get(name)
+    flags = None if (experiments or defines) else STRATEGIES[name]
     out, meta = variant_path(name), variant_path(name)[:-3] + ".json"
     os.makedirs(os.path.dirname(out), exist_ok=True)
 
@@ -185,11 +189,13 @@ def build_variant(name: str, force: bool = False) -> dict:
             if res is not None:
                 return res
             tmp = os.path.relpath(out, _CSRC) + f".tmp{os.getpid()}"
-            cmd = ["make", "-C", _CSRC, "-B", tmp, f"OUT={tmp}"] + (["EXTRA=-DNMPC_EXPERIMENTS"] if experiments else ["SCHED=" + " ".join(flags)])
+            cmd = ["make", "-C", _CSRC, "-B", tmp, f"OUT={tmp}"] + (["EXTRA=-DNMPC_EXPERIMENTS"] if experiments else
+                                                                  ["EXTRA=" + " ".join(defines)] if defines else ["SCHED=" + " ".join(flags)])
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"building {out} failed:\n" + r.stdout[-2000:] + r.stderr[-4000:])
-            res = codegen_check.verify(codegen_check.makefile_flags() + ["-DNMPC_EXPERIMENTS"]) if experiments else codegen_check.verify(flags)
+            res = (codegen_check.verify(codegen_check.makefile_flags() + (["-DNMPC_EXPERIMENTS"] if experiments else defines))
+                   if (experiments or defines) else codegen_check.verify(flags))
             res.pop("resources", None)
             res["source_hash"] = source_hash()
             res["variant_key"] = _variant_key()

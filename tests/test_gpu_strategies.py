@@ -88,6 +88,41 @@ def test_headline_kernel_has_tested_fallback_strategies(strategy):
     assert res["sample_equals_oracle"] and res["permutation_invariant"] and res["scrub_independent"], res
 
 
+@pytest.mark.parametrize("config", ["cfg1", "cfg2"])
+def test_full_scan_build_gives_the_same_bits(config):
+    """-DNMPC_WIN=0 (a documented setting of the kernels: the cross-track search always as the full scan) keeps the obstacle certificate, and with
+    it the helper-side guard of what a helper lane has learnt about an owner's tables: that guard must not depend on the window being compiled in
+    (advisor, round 5).  Same bits as the oracle on a sample, permutation-invariant, scrub-independent -- and a small batch in the team mode (every
+    instance with three helpers from its first iteration) equals the oracle instance for instance."""
+    from mpc_trajectory_generator_amd import _lib
+    check = _lib.build_variant("win0")
+    assert check.get("ok"), f"code-generation check failed for the -DNMPC_WIN=0 build: {check}"
+    res = run_probe(_lib.variant_path("win0"), config)
+    assert res["sample_equals_oracle"] and res["permutation_invariant"] and res["scrub_independent"], res
+    small = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from conftest import oracle_for, STATUS_FIELDS
+from mpc_trajectory_generator_amd import named_config
+from mpc_trajectory_generator_amd.solver import BatchSolver
+from mpc_trajectory_generator_amd.harness import synthetic_batch
+cfg = named_config(sys.argv[1])
+P = synthetic_batch(cfg, 11, 40, 4711)
+s = BatchSolver(cfg, max_batch=64)
+ok = True
+for rep in range(3):
+    u, y, st = s.solve(P)
+    uo, yo, sto = oracle_for(cfg).solve_batch(P, threads=16)
+    ok = ok and bool(np.array_equal(u, uo) and np.array_equal(y, yo) and all(np.array_equal(st[f], sto[f]) for f in STATUS_FIELDS))
+print(json.dumps({"ok": ok}))
+"""
+    r = subprocess.run([sys.executable, "-c", small, config], cwd=ROOT, env=dict(os.environ, NMPC_LIB_PATH=_lib.variant_path("win0")),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().split("\n")[-1])["ok"]
+
+
 def test_headline_kernels_do_not_read_what_they_did_not_write():
     """The shipped library, all four BASELINE configurations: the results do not depend on the register / LDS content left by earlier waves."""
     r = subprocess.run([sys.executable, "scripts/scrub_probe.py", "shipped", "cfg1", "cfg3", "cfg4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
