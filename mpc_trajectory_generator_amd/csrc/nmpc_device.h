@@ -303,6 +303,30 @@ __device__ __forceinline__ double group_prefix_ex<20>(double v, int lane, double
     return incl;
 }
 
+// The same for a wave whose lanes 60..63 (stages 20..23 of group 2: beyond every horizon) hold ZEROS in `v` -- the hybrid kernel's owner
+// path, whose query points arrive through LDS with zero pads in those places.  The inclusive sum of lane 60 is then +0.0 exactly (the
+// masked first level adds +0.0 to whichever sign the zero came with), so the lanes of rows 0..2 fetch their "carry" from lane 60 instead
+// of from themselves and the addition needs no select: v + (+0.0) is the very operation the select form performs.  Same bits, two
+// v_cndmask less per scan.
+__device__ __forceinline__ double group_prefix_ex_z60(double v, int lane, double &excl)
+{
+    const bool tail = lane >= 48;
+    double o = dpp_mov<0x111>(v);
+    v = v + ((tail && (lane & 3) < 1) ? 0.0 : o);
+    o = dpp_mov<0x112>(v);
+    v = v + ((tail && (lane & 3) < 2) ? 0.0 : o);
+    o = dpp_mov_old<0x114, 0x7>(zero_pair(), v);
+    v = v + o;
+    o = dpp_mov_old<0x118, 0x7>(o, v);
+    v = v + o;
+    const int q = (lane - 48) >> 2;
+    const double carry = lane_get(v, (tail && lane < 60) ? 16 * q + 15 : 60);       // last entry of block 0 | the +0.0 of lane 60
+    const double incl = v + carry;
+    const double sh = dpp_mov<0x111>(incl);
+    excl = (tail && (lane & 3) == 0) ? carry : sh;
+    return incl;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sin and cos: Cody-Waite reduction by pi/2 in three fma steps + fdlibm minimax kernels (Horner, fma)
 // ---------------------------------------------------------------------------------------------

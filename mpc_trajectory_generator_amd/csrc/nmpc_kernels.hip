@@ -55,7 +55,7 @@ constexpr double LBFGS_CBFGS_EPSILON = 1e-8;
 
 // LDS slice of one group (offsets in doubles)
 struct LdsMap {
-    int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw
+    int sc;      // 18 instance scalars: x0 y0 th0 vinit winit xf yf thf | q qv qth rv rw qN qthN qcte pa pw | vinit winit again, as an aligned pair
     int cw;      // CW_NCOEF sin/cos polynomial coefficients (nmpc_device.h)
     int par;     // up to 24 parked solver scalars (hybrid kernel)
     int seg;     // SEG_STRIDE = 5 per reference segment (40 B): s1x s1y dx dy 1/(|d|^2 + 1e-16)
@@ -206,6 +206,7 @@ __device__ __forceinline__ void prepare_instance(const KArgs &a, lds_double *L, 
     const LdsMap mp = the_map<SH, P>(a);
     if (t < 8) L[mp.sc + t] = p[t];                      // state, last input, target (p[8:10] unused)
     if (t >= 8 && t < 18) L[mp.sc + t] = p[t + 2];       // ten weights p[10:20]
+    if (t == 18 || t == 19) L[mp.sc + t] = p[t - 15];    // the last input once more, as a (v, w) pair: "the stage before stage 0" of the hybrid kernel's transport
     if (t < CW_NCOEF) L[mp.cw + t] = CW_COEF_DEV[t];
     NMPC_WAVE_SYNC();
     vref = t < N ? p[NZ + t] : 0.0;
@@ -361,13 +362,24 @@ __device__ __forceinline__ int scalar_own(int x)
     asm volatile("" : "+v"(x));
     return __builtin_amdgcn_readfirstlane(x);
 }
-template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, int WIN = 0>
+// What the hybrid kernel's owner path hands over because its query points travel through LDS (nmpc_solve_hyb.h, "transport"): the control
+// pair of the stage before (the last input for stage 0) -- read from the transport area one slot down instead of fetched from the neighbour
+// lane --, this lane's slot of the area for handing (qa, qw) to the stage before, and the slot of the stage after (a zero pad behind the
+// last stage).  Two pointers that the compiler cannot tell apart: the write stays in front of the read, and LDS serves a wave in order.
+// Lanes 60..63 of such an evaluation hold zeros in zv, zw (Z60: group_prefix_ex_z60).
+struct EvX {
+    double vprev, wprev;
+    lds_double2 *mine;
+    const lds_double2 *next;
+};
+template <int P, class SH = ShapeAny, bool WRITE_F2 = false, bool CULL = false, int WIN = 0, bool Z60 = false>
 __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2off, int lane, int t, double zv, double zw,
                                          double c, double cbar_inv, double yv, double yw, double vref, const DynStage &dyn,
                                          bool want_grad, double &psi, double &pen_out, double &gv,
                                          double &gw, double &av_out, double &aw_out, unsigned long long near = ~0ull, WinState *ws = nullptr,
-                                         ObsCert *oc = nullptr, long long *nmpc_pe = nullptr, const EvK *ek = nullptr)
+                                         ObsCert *oc = nullptr, long long *nmpc_pe = nullptr, const EvK *ek = nullptr, const EvX *evx = nullptr)
 {
+    static_assert(!Z60 || P == 20, "zero pads in lanes 60..63: the tri layout only");
     const int N = shape_N<SH>(a), nobs = shape_nobs<SH>(a), ndyn = shape_ndyn<SH>(a);
     const LdsMap mp = the_map<SH, P>(a);
     const double ts = ek ? ek->ts : a.pb.ts, inv_ts = ek ? ek->inv_ts : a.inv_ts;
@@ -386,12 +398,16 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     // (the pre-update state of a stage is the post-update state of the stage before: the same fma on the prefix sum of the stage before,
     // which the scan hands over with its own carry exchange -- group_prefix_ex)
     double ew_, ex_, ey_;
-    const double thn = fma(ts, group_prefix_ex<P>(zw, lane, ew_), th0);
+    auto prefix_ex = [lane](double v, double &excl) {
+        if constexpr (Z60) return group_prefix_ex_z60(v, lane, excl);
+        else return group_prefix_ex<P>(v, lane, excl);
+    };
+    const double thn = fma(ts, prefix_ex(zw, ew_), th0);
     const double th = t == 0 ? th0 : fma(ts, ew_, th0);
     double sn, cs;
     sincos_cw_t(th, (const lds_double *)(L + mp.cw), sn, cs);
-    const double xn = fma(ts, group_prefix_ex<P>(zv * cs, lane, ex_), x0);
-    const double yn = fma(ts, group_prefix_ex<P>(zv * sn, lane, ey_), y0);
+    const double xn = fma(ts, prefix_ex(zv * cs, ex_), x0);
+    const double yn = fma(ts, prefix_ex(zv * sn, ey_), y0);
     const double xp = t == 0 ? x0 : fma(ts, ex_, x0);
     const double yp = t == 0 ? y0 : fma(ts, ey_, y0);
 
@@ -512,8 +528,8 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     NMPC_EVTICK(1);     // stage cost + CTE loop
     acc = fma(sc[SC_QCTE], best, acc);                                            // (:144)
     // accelerations (:160-161), their cost (:170-171) and the ALM term
-    const double vprev = from_prev<P>(zv, lane, sc[SC_VINIT]);
-    const double wprev = from_prev<P>(zw, lane, sc[SC_WINIT]);
+    const double vprev = evx ? evx->vprev : from_prev<P>(zv, lane, sc[SC_VINIT]);
+    const double wprev = evx ? evx->wprev : from_prev<P>(zw, lane, sc[SC_WINIT]);
     double av = (zv - vprev) * inv_ts, aw = (zw - wprev) * inv_ts;
     acc = fma(sc[SC_PA] * av, av, acc);
     acc = fma(sc[SC_PW] * aw, aw, acc);
@@ -736,7 +752,9 @@ __device__ __forceinline__ void eval_psi(const KArgs &a, lds_double *L, int f2of
     const double e = fma(Sy, cs, -(Sx * sn));
     const double Dt = in ? (ts * zv) * e : 0.0;
     const double St = group_suffix<P>(in ? gt + from_next<P>(Dt, lane) : 0.0, lane);
-    const double qan = from_next<P>(qa, lane), qwn = from_next<P>(qw, lane);
+    double qan, qwn;
+    if (evx) { *evx->mine = dbl2{qa, qw}; const dbl2 n_ = *evx->next; qan = n_.x; qwn = n_.y; }
+    else { qan = from_next<P>(qa, lane); qwn = from_next<P>(qw, lane); }
     const double dynv = fma(Sx, cs, Sy * sn);
     double g1 = fma(2.0 * sc[SC_RV], zv, (2.0 * sc[SC_QV]) * dv);
     g1 = fma(inv_ts, qa - qan, g1);

@@ -7,7 +7,9 @@
 // kernel: stage t at lane t of BOTH 32-lane halves, so every reduction of the PANOC / L-BFGS code is a
 // pure DPP + permlane tree (no LDS round trip; the tri layout's row <-> tail exchange costs one per
 // reduction, and the two-loop recursion alone chains twenty of them per iteration).  Query points are
-// carried from the state layout to the evaluation layout, and gradients back, with ds_bpermute:
+// carried from the state layout to the evaluation layout, and gradients back, THROUGH LDS (the "transport" area: the place of the Gram
+// batch's four vectors, which are dead between the batch and the next step) -- two ds_write_b128 and two ds_read_b128 where the
+// ds_bpermute form took twelve cross-lane fetches and eight selects, and the kernel is bound by instruction issue:
 //   X = per-half point (half 0 / half 1 prepare different points), Y = a third point known to both.
 //   initialisation   X = (u | u + h)                 Y = u
 //   iteration >= 1   X = (u_bar | u+(tau = 1))       Y = u+(tau = 1/2)
@@ -68,11 +70,12 @@ __device__ __forceinline__ double point_scalar(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
-// gradient pair of query point k's evaluation, delivered to the state layout (zero beyond the horizon)
-#define NMPC_FETCH_GRAD(SRC, OV, OW)                                           \
+// gradient pair of query point K's evaluation, delivered to the state layout: one read of the transport area (lanes beyond the
+// twentieth stage read the point's zero pad; stages N.. of a shorter horizon hold zeros, as the evaluation left them)
+#define NMPC_FETCH_GRAD(K, OV, OW)                                             \
     do {                                                                       \
-        const double fv_ = lane_get(egv, (SRC)), fw_ = lane_get(egw, (SRC));   \
-        OV = in ? fv_ : 0.0; OW = in ? fw_ : 0.0;                              \
+        const dbl2 fg_ = zgr[(K) * ZS];                                        \
+        OV = fg_.x; OW = fg_.y;                                                \
     } while (0)
 
 // gradient step x - gamma g and its projection on U (lanes beyond the horizon stay zero)
@@ -269,10 +272,22 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     const LdsMap mp = the_map<SH, PE>(a);
     const int n2 = shape_nobs<SH>(a) + shape_ndyn<SH>(a);
     const int f2off = mp.f2 + q * (n2 + 1);
-    // evaluation-layout lane that holds stage t of query point 0 / 1 / 2 (state lanes beyond the horizon: themselves)
-    const int src0 = in ? lay_lane<PE>(0, t) : lane, src1 = in ? lay_lane<PE>(1, t) : lane, src2 = in ? lay_lane<PE>(2, t) : lane;
-    // state-layout lane that holds this evaluation lane's query point: X of half q (points 0, 1), Y (point 2)
-    const int zsrcX = ine ? (q < 2 ? 32 * q + te : te) : lane, zsrcY = ine ? te : lane;
+    // Transport area: [3 points][ZS = 24 slots] (v, w) pairs + 8 slots nobody reads = the 80 pairs of the Gram batch's s | y | r | g, which
+    // are dead from the end of the batch to the next step.  Slot (k, j) holds stage j of point k; slots 20..23 of a point are ZERO PADS:
+    // state lanes 20..23 write their (zero) entries there with the query points, and nothing else ever does -- evaluation lanes 60..63
+    // (stages 20..23 of point 2) and state lanes 24..31 write to the spare slots.  Every pointer below is a per-lane constant.
+    constexpr int ZS = 24, src0 = 0, src1 = 1, src2 = 2;
+    static_assert(3 * ZS + 8 == 4 * GRAM_NST, "the transport area is the place of the Gram batch's four vectors");
+    lds_double2 *Lz = (lds_double2 *)(L + mp.nv);
+    lds_double2 *zwX = Lz + (t < ZS ? h * ZS + t : 3 * ZS + (t - ZS));          // state lane: its X entry -> point h (X of half 0 | half 1)
+    lds_double2 *zwY = Lz + (t < ZS ? 2 * ZS + t : 3 * ZS + (t - ZS));          // ... its Y entry -> point 2
+    const lds_double2 *zrd = Lz + q * ZS + te;                                   // evaluation lane: its stage of its point (lanes 60..63: zero pads)
+    // ... the stage before it: the last input (prepare_instance leaves it as a pair behind the instance scalars) for stage 0
+    const lds_double2 *zpv = te == 0 ? (const lds_double2 *)(L + mp.sc + 18) : (lane < 60 ? zrd - 1 : zrd);
+    lds_double2 *zmine = Lz + (lane < 60 ? q * ZS + te : 3 * ZS + (lane - 60));   // evaluation lane: where it leaves (qa, qw), then its gradient pair
+    // ... and the slot of the stage after it, as an address of its own: the compiler must not prove the read independent of the write
+    const lds_double2 *znext = Lz + opaque_i(lane < 60 ? q * ZS + te + 1 : 3 * ZS + (lane - 60) + 1);
+    const lds_double2 *zgr = Lz + (t < 20 ? t : 20);                             // state lane: gradient of point k at zgr[k * ZS]
     // L-BFGS ring: GRAM_NST + 1 columns per slot, the last one all zeros -- lanes beyond GRAM_NST read it (stages N.. are zeros too)
     constexpr int NS = GRAM_NST + 1;
     const int tt = t < GRAM_NST ? t : GRAM_NST;
@@ -759,16 +774,19 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #endif
             const dbl2 ycur = *Ly;
             const double yv = ycur.x, yw = ycur.y;
-            // query points: state layout -> evaluation layout
-            const double zXv = lane_get(xv, zsrcX), zXw = lane_get(xw, zsrcX);
-            const double zYv = lane_get(yqv, zsrcY), zYw = lane_get(yqw, zsrcY);
-            const double zv = q == 2 ? zYv : zXv, zw = q == 2 ? zYw : zXw;
+            // query points: state layout -> evaluation layout (transport area; LDS serves the accesses of a wave in order)
+            *zwX = dbl2{xv, xw};
+            *zwY = dbl2{yqv, yqw};
+            const dbl2 zq_ = *zrd, zp_ = *zpv;
+            const double zv = zq_.x, zw = zq_.y;
+            const EvX evx = {zp_.x, zp_.y, zmine, znext};
 #if defined(NMPC_PROF2) && NMPC_PROF2 == 2
             NMPC_SEC_RAW(pe[7]);
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, pe, &ek);
+            eval_psi<PE, SH, false, CULL, WIN, true>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, pe, &ek, &evx);
 #else
-            eval_psi<PE, SH, false, CULL, WIN>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, nullptr, &ek);
+            eval_psi<PE, SH, false, CULL, WIN, true>(a, L, f2off, lane, te, zv, zw, pen_c, cbar_inv, yv, yw, *Lvr, dyn, need_grad, psi, pen, egv, egw, eav, eaw, near, &ws, OBSC ? &oc : nullptr, nullptr, &ek, &evx);
 #endif
+            *zmine = dbl2{egv, egw};                 // gradients: evaluation layout -> state layout (NMPC_FETCH_GRAD)
 #ifdef NMPC_PROF2
             { double keep = psi + egv; asm volatile("" : "+v"(keep)); }
 #endif
