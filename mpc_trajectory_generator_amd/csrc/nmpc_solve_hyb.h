@@ -169,6 +169,13 @@ __device__ __forceinline__ void fma2_row_bcast(double &a1, double &a2, double x,
         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
         : "+v"(a1), "+v"(a2) : "v"(x), "v"(y1), "v"(y2), "v"(after), "n"(J));
 }
+template <int J>
+__device__ __forceinline__ void fnma2_row_bcast(double &a1, double &a2, double x, double y1, double y2, double after)
+{
+    asm("v_fmac_f64_dpp %0, -%2, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, -%2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+        : "+v"(a1), "+v"(a2) : "v"(x), "v"(y1), "v"(y2), "v"(after), "n"(J));
+}
 // (the two-stage kernel's: two stages per lane)
 template <int J>
 __device__ __forceinline__ void fnma5_row_bcast(double &a1, double &a2, double &a3, double &a4, double &a5, double x, double y1, double y2, double y3,
@@ -198,39 +205,87 @@ __device__ __forceinline__ double lane_scalar(double v, int ln)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), ln);
     return __hiloint2double(hi, lo);
 }
-// one step of the first / second recurrence (J = age of the pair, H = the ring's head) with the direction's update of that step.  The pair of
-// age J sits in ring slot (H + J) mod 10: with H a compile-time constant every LDS address of a step is a per-lane base plus an immediate --
-// so the twenty steps exist once per head position (a ten-way switch on the wave-uniform head), 3 scalar and 2 vector address instructions
-// per step less than with the head in a register: the kernel is bound by instruction issue of ANY class.
-#define NMPC_GRAM_FWD(H, J)                                                                    \
-    do {                                                                                       \
-        constexpr int pj_ = ((H) + (J)) % MAXMEM;                                              \
-        const double gs_ = Lgsy[pkrow + pj_], gy_ = Lgyy[pkrow + pj_];                         \
-        const dbl2 yp_ = LY[pj_ * NS + tt];                                                    \
-        const double al_ = rho_k * ga1;                                                        \
-        ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                                              \
-        fnma3_row_bcast<(J)>(ga2, dv, dw, al_, gy_, yp_.x, yp_.y, ga1);                        \
-    } while (0)
-#define NMPC_GRAM_BWD(H, J)                                                                    \
-    do {                                                                                       \
-        constexpr int pj_ = ((H) + (J)) % MAXMEM;                                              \
-        const double gr_ = Lgsy[pj_ * GRAM_LD + pk_];                                           \
-        const dbl2 sp_ = LS[pj_ * NS + tt];                                                    \
-        const double be_ = rho_k * ga2;                                                        \
-        const double ab_ = alv - be_;                                                          \
-        ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                                               \
-        fma2_row_bcast<(J)>(dv, dw, ab_, sp_.x, sp_.y, ga2);                                   \
-    } while (0)
+// The recurrences, software-pipelined.  A step's coefficient (al_J = rho ga1, ab_J = alpha - rho ga2) is read through DPP by the instruction
+// that follows it, which needs two wait states after the write; the updates of the direction and of the other recurrence that belong to the
+// step BEFORE are independent of it, so they are issued in that gap instead of an s_nop: every accumulator still receives its updates in
+// the two-loop recursion's order (same bits), a step is one instruction shorter and its dependent chain one slot.  The compiler does not
+// see into the statements: codegen_check.py checks the wait states of every DPP read in the final assembly.
+//   first recurrence, step J >= 1: al = rho ga1 | dv, dw -= al_prev[J-1] (yp.x, yp.y)_prev | ga1 -= al[J] gs | ga2 -= al[J] gy
+template <int J>
+__device__ __forceinline__ double gram_fwd_step(double &ga1, double &ga2, double &dv, double &dw, double rho, double gs, double gy, double alp,
+                                                double ypx, double ypy)
+{
+    double al;
+    asm("v_mul_f64 %0, %5, %1\n\t"
+        "v_fmac_f64_dpp %3, -%8, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, -%8, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, -%0, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, -%0, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+        : "=&v"(al), "+v"(ga1), "+v"(ga2), "+v"(dv), "+v"(dw)
+        : "v"(rho), "v"(gs), "v"(gy), "v"(alp), "v"(ypx), "v"(ypy), "n"(J), "n"(J - 1));
+    return al;
+}
+// (step 0 has no step before it: the two wait states are an s_nop)
+__device__ __forceinline__ double gram_fwd_first(double &ga1, double &ga2, double rho, double gs, double gy)
+{
+    double al;
+    asm("v_mul_f64 %0, %3, %1\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %1, -%0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, -%0, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf"
+        : "=&v"(al), "+v"(ga1), "+v"(ga2) : "v"(rho), "v"(gs), "v"(gy));
+    return al;
+}
+//   second recurrence, step J <= 8 (the step before it is J + 1): ab = alpha - rho ga2 | dv, dw += ab_prev[J+1] (sp.x, sp.y)_prev | ga2 += ab[J] gr
+template <int J>
+__device__ __forceinline__ double gram_bwd_step(double &ga2, double &dv, double &dw, double rho, double alv, double gr, double abp, double spx,
+                                                double spy)
+{
+    double ab;
+    asm("v_mul_f64 %0, %4, %1\n\t"
+        "v_add_f64 %0, %5, -%0\n\t"
+        "v_fmac_f64_dpp %2, %7, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %7, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %0, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+        : "=&v"(ab), "+v"(ga2), "+v"(dv), "+v"(dw)
+        : "v"(rho), "v"(alv), "v"(gr), "v"(abp), "v"(spx), "v"(spy), "n"(J), "n"(J + 1));
+    return ab;
+}
+// The pair of age J sits in ring slot (H + J) mod 10: with H, the ring's head, a compile-time constant every LDS address of a step is a per-lane
+// base plus an immediate -- so the twenty steps exist once per head position (a ten-way switch on the wave-uniform head), 3 scalar and 2
+// vector address instructions per step less than with the head in a register: the kernel is bound by instruction issue of ANY class
+// (DESIGN.md section 5.6).
+#define NMPC_GRAM_LDF(H, J)                                                                    \
+        constexpr int fp##J = ((H) + (J)) % MAXMEM;                                            \
+        const double fgs##J = Lgsy[pkrow + fp##J], fgy##J = Lgyy[pkrow + fp##J];               \
+        const dbl2 fyp##J = LY[fp##J * NS + tt]
+#define NMPC_GRAM_FWD(H, J, JP)                                                                \
+        NMPC_GRAM_LDF(H, J);                                                                   \
+        const double fal##J = gram_fwd_step<(J)>(ga1, ga2, dv, dw, rho_k, fgs##J, fgy##J, fal##JP, fyp##JP.x, fyp##JP.y)
+#define NMPC_GRAM_LDB(H, J)                                                                    \
+        constexpr int bp##J = ((H) + (J)) % MAXMEM;                                            \
+        const double bgr##J = Lgsy[bp##J * GRAM_LD + pk_];                                     \
+        const dbl2 bsp##J = LS[bp##J * NS + tt]
+#define NMPC_GRAM_BWD(H, J, JP)                                                                \
+        NMPC_GRAM_LDB(H, J);                                                                   \
+        const double bab##J = gram_bwd_step<(J)>(ga2, dv, dw, rho_k, alv, bgr##J, bab##JP, bsp##JP.x, bsp##JP.y)
 // both recurrences for the head position H
 #define NMPC_GRAM_BOTH(H)                                                                                                            \
     do {                                                                                                                             \
-        NMPC_GRAM_FWD(H, 0); NMPC_GRAM_FWD(H, 1); NMPC_GRAM_FWD(H, 2); NMPC_GRAM_FWD(H, 3); NMPC_GRAM_FWD(H, 4);                     \
-        NMPC_GRAM_FWD(H, 5); NMPC_GRAM_FWD(H, 6); NMPC_GRAM_FWD(H, 7); NMPC_GRAM_FWD(H, 8); NMPC_GRAM_FWD(H, 9);                     \
+        NMPC_GRAM_LDF(H, 0);                                                                                                         \
+        const double fal0 = gram_fwd_first(ga1, ga2, rho_k, fgs0, fgy0);                                                             \
+        NMPC_GRAM_FWD(H, 1, 0); NMPC_GRAM_FWD(H, 2, 1); NMPC_GRAM_FWD(H, 3, 2); NMPC_GRAM_FWD(H, 4, 3); NMPC_GRAM_FWD(H, 5, 4);      \
+        NMPC_GRAM_FWD(H, 6, 5); NMPC_GRAM_FWD(H, 7, 6); NMPC_GRAM_FWD(H, 8, 7); NMPC_GRAM_FWD(H, 9, 8);                              \
+        fnma2_row_bcast<9>(dv, dw, fal9, fyp9.x, fyp9.y, ga1);                                                                      \
         const double alv = rho_k * ga1;          /* alpha_k in lane k: entry k of ga1 is final once step k has used it */              \
         ga2 = n_H0 * ga2;                                                                                                            \
         dv = n_H0 * dv; dw = n_H0 * dw;                                                                                              \
-        NMPC_GRAM_BWD(H, 9); NMPC_GRAM_BWD(H, 8); NMPC_GRAM_BWD(H, 7); NMPC_GRAM_BWD(H, 6); NMPC_GRAM_BWD(H, 5);                     \
-        NMPC_GRAM_BWD(H, 4); NMPC_GRAM_BWD(H, 3); NMPC_GRAM_BWD(H, 2); NMPC_GRAM_BWD(H, 1); NMPC_GRAM_BWD(H, 0);                     \
+        NMPC_GRAM_LDB(H, 9);                                                                                                         \
+        const double bab9 = alv - rho_k * ga2;                                                                                       \
+        ga2 = fma_row_bcast<9>(ga2, bab9, bgr9);                                                                                     \
+        NMPC_GRAM_BWD(H, 8, 9); NMPC_GRAM_BWD(H, 7, 8); NMPC_GRAM_BWD(H, 6, 7); NMPC_GRAM_BWD(H, 5, 6); NMPC_GRAM_BWD(H, 4, 5);      \
+        NMPC_GRAM_BWD(H, 3, 4); NMPC_GRAM_BWD(H, 2, 3); NMPC_GRAM_BWD(H, 1, 2); NMPC_GRAM_BWD(H, 0, 1);                              \
+        fma2_row_bcast<0>(dv, dw, bab0, bsp0.x, bsp0.y, ga2);                                                                        \
     } while (0)
 
 // The state machine's wave-uniform flags are bits of ONE 32-bit scalar.  As `bool`s each is a 64-bit lane mask (two scalar registers,
@@ -491,6 +546,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             double xv = 0, xw = 0, yqv = 0, yqw = 0;       // query points of this pass: a phase handler below sets them
             double nr2 = 0, norm_r = 0;                    // ||r||^2, ||r|| of the step this pass starts (the batch below); the last ||r|| stays in pk_last_fpr
             double pv = 0, pw = 0;                         // line-search trial point being consumed (after the evaluation)
+            // (Measured and not taken, round 6: these without their initialisers -- each is written before it is read on every path, and the
+            // zeros are fifteen moves per pass in front of the phase handlers.  Without those of xv..yqw or of nr2, norm_r ROCm 7.2's
+            // register allocator segfaults or spills to scratch; those of pv, pw, lhs the compiler drops by itself.)
             // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
             bool lb_batch = false;                     // this pass starts with the batch of inner products (f_back, f_begin)
             if (f_back) {
@@ -503,7 +561,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
                 pk_hig = 0.5 / gamma;
                 NMPC_HALF_STEP(uv, uw);
-                rv = uv - hv; rw = uw - hw;
                 lb_batch = true;
             }
             // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1) | (tau/4, ls_n+2)
@@ -540,7 +597,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 }
             }
             // ---------------------------------------------------------------- start of a PANOC step
-            if (f_begin) { rv = uv - hv; rw = uw - hw; lb_batch = true; }
+            if (f_begin) lb_batch = true;
 #ifdef NMPC_TL
             if (f_begin) { tl_it++; NMPC_TL_EV(tl_it, 0); }
 #endif
@@ -548,6 +605,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             // ---- the batch of inner products of this step (Gram-form L-BFGS, see the top of the file)
             double gU = 0.0, gs1 = 0.0, gs2 = 0.0, gy1 = 0.0, gy2 = 0.0;
             if (lb_batch) {
+                rv = uv - hv; rw = uw - hw;                // the residual of the step (a back-off has just halved gamma and renewed the half step)
                 if (f_begin && iteration >= 1 && !lb_first) {
                     const dbl2 os_ = *Los, og_ = *Log;
                     gs1 = uv - os_.x; gs2 = uw - os_.y; gy1 = rv - og_.x; gy2 = rw - og_.y;
@@ -1233,6 +1291,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #undef NMPC_FETCH_GRAD
 #undef NMPC_LB_ZERO
 #undef NMPC_GRAM_FWD
+#undef NMPC_GRAM_LDF
+#undef NMPC_GRAM_LDB
 #undef NMPC_GRAM_BWD
 #undef NMPC_GRAM_BOTH
 #undef NMPC_TAKE_TRIAL
