@@ -314,7 +314,12 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
     const int q = lay_group<PE>(lane), te = lay_stage<PE>(lane);
     // (launch-uniform integers the loop reads -- each a scalar of its own, not a member of the argument block's eight-dword load: scalar_own)
     const int N = shape_N<SH>(a), m = scalar_own(a.op.lbfgs_memory);
-    const int k_akkt = scalar_own(a.op.akkt_gradient), k_lsf = scalar_own(a.op.ls_failure), k_help = scalar_own(a.team_help), k_dbg = scalar_own(a.dbg);
+    const int k_akkt = scalar_own(a.op.akkt_gradient), k_lsf = scalar_own(a.op.ls_failure);
+#ifdef NMPC_EXPERIMENTS
+    const int k_help = scalar_own(a.team_help), k_dbg = scalar_own(a.dbg);      // knobs of the experiments build (NMPC_TEAM_HELP, NMPC_DEBUG_PRIO)
+#else
+    constexpr int k_help = 1, k_dbg = 0;                                          // (the shipped library's host side never sets them otherwise)
+#endif
     const bool in = t < N, ina = in;            // state layout: lanes beyond the horizon hold zeros
     const bool ine = te < N;                    // evaluation layout: a real stage
     // with a 20-stage horizon every stage lane of the evaluation layout is inside it (lanes 60..63 may
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
         }
 
         // phase flags (wave-uniform): set by the state handlers, consumed at the top of the loop
-        FlagBit f_start{fl, 1u << 7}, f_back{fl, 1u << 8}, f_trials{fl, 1u << 9}, f_end{fl, 1u << 10}, f_begin{fl, 1u << 11}, f_done{fl, 1u << 12}, f_fb{fl, 1u << 13};
+        FlagBit f_start{fl, 1u << 7}, f_back{fl, 1u << 8}, f_trials{fl, 1u << 9}, f_begin{fl, 1u << 11}, f_done{fl, 1u << 12}, f_fb{fl, 1u << 13};
         FlagBit running{fl, 1u << 14}, timed_out{fl, 1u << 15};
         f_start = true; running = true;
         FlagBit posted{fl, 1u << 16};                      // a request of the current iteration is open for the helpers
@@ -542,6 +547,19 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #define NMPC_SEC(acc) do { } while (0)
 #endif
 
+        // an iteration finished (raised by the consumption of a pass; the next pass starts the next step or returns from the inner solver).
+        // Written out where it is raised: as a flag it was a test at the top of every pass and a set / clear pair per iteration.
+        // OpEn: while step() && num_iter < max_iter { num_iter++ };  opts.max_total_inner: the deterministic max_duration
+#define NMPC_END_ITERATION()                                                                                   \
+        do {                                                                                                   \
+            iteration++;                                                                                       \
+            if (!(num_iter < max_inner)) f_done = true;                                                        \
+            else {                                                                                             \
+                num_iter++;                                                                                    \
+                if (budget > 0u && inner_total + num_iter >= budget) { timed_out = true; f_done = true; }      \
+                else f_begin = true;                                                                           \
+            }                                                                                                  \
+        } while (0)
         for (;;) {
             double xv = 0, xw = 0, yqv = 0, yqw = 0;       // query points of this pass: a phase handler below sets them
             double nr2 = 0, norm_r = 0;                    // ||r||^2, ||r|| of the step this pass starts (the batch below); the last ||r|| stays in pk_last_fpr
@@ -549,19 +567,31 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
             // (Measured and not taken, round 6: these without their initialisers -- each is written before it is read on every path, and the
             // zeros are fifteen moves per pass in front of the phase handlers.  Without those of xv..yqw or of nr2, norm_r ROCm 7.2's
             // register allocator segfaults or spills to scratch; those of pv, pw, lhs the compiler drops by itself.)
-            // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
             bool lb_batch = false;                     // this pass starts with the batch of inner products (f_back, f_begin)
-            if (f_back) {
-                if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }      // speculation discarded
-                lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
-                NMPC_LB_ZERO();
-                fbe_ok = false;
-                pk_Lc *= 2.0; gamma /= 2.0;
-                pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-                pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
-                pk_hig = 0.5 / gamma;
-                NMPC_HALF_STEP(uv, uw);
-                lb_batch = true;
+            // (the two rare phases behind ONE test: a pass of the bulk looks at one flag word instead of two flags)
+            if (fl & (f_back.bit | f_fb.bit)) {
+                // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
+                if (f_back) {
+                    if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }      // speculation discarded
+                    lb_active = 0; lb_first = true;                         // L-BFGS buffer invalidated
+                    NMPC_LB_ZERO();
+                    fbe_ok = false;
+                    pk_Lc *= 2.0; gamma /= 2.0;
+                    pk_sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                    pk_c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                    pk_hig = 0.5 / gamma;
+                    NMPC_HALF_STEP(uv, uw);
+                    lb_batch = true;
+                }
+                // ---------------------------------------------------------------- every trial failed (opts.ls_failure = 1):
+                // tau = 0, the forward-backward step from the current iterate
+                if (f_fb) {
+                    f_fb = false;
+                    tau = 0.0;
+                    { const dbl2 gk_ = *Lgk; gv = gk_.x; gw = gk_.y; }
+                    NMPC_HALF_STEP(uv, uw);
+                    xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
+                }
             }
             // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1) | (tau/4, ls_n+2)
             if (f_trials) {
@@ -573,28 +603,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 yqv = fma(-t4_, dv, fma(-om4_, rv, uv));
                 yqw = fma(-t4_, dw, fma(-om4_, rw, uw));
                 need_grad = true; state = D_LS;
-            }
-            // ---------------------------------------------------------------- every trial failed (opts.ls_failure = 1):
-            // tau = 0, the forward-backward step from the current iterate
-            if (f_fb) {
-                f_fb = false;
-                tau = 0.0;
-                { const dbl2 gk_ = *Lgk; gv = gk_.x; gw = gk_.y; }
-                NMPC_HALF_STEP(uv, uw);
-                xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
-            }
-            // ---------------------------------------------------------------- an iteration finished
-            if (f_end) {
-                f_end = false;
-                iteration++;
-                // OpEn: while step() && num_iter < max_iter { num_iter++ }
-                if (!(num_iter < max_inner)) f_done = true;
-                else {
-                    num_iter++;
-                    // opts.max_total_inner: the deterministic max_duration
-                    if (budget > 0u && inner_total + num_iter >= budget) { timed_out = true; f_done = true; }
-                    else f_begin = true;
-                }
             }
             // ---------------------------------------------------------------- start of a PANOC step
             if (f_begin) lb_batch = true;
@@ -649,11 +657,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #ifdef NMPC_TL
             if (lb_batch) { NMPC_TL_KEEP(norm_r + gU); NMPC_TL_EV(tl_it, 1); }
 #endif
-            if (f_back) {
-                f_back = false;
-                lip_it++;
-                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
-            }
             if (f_begin) {
                 f_begin = false;
                 bool exit_now = false;
@@ -781,32 +784,40 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                     }
                 }
             }
-            // ---------------------------------------------------------------- the inner solver returned
-            if (f_done) {
-                f_done = false;
-                inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
-                                         : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
-                inner_total += num_iter;
-                pk_last_cost = cost;                                     // (pk_last_fpr: the norm of the last step started)
-                uv = hv; uw = hw;                                        // PANOC returns the feasible half step
-                const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(pk_last_fpr);
-                if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
-                else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
-            }
-            // ---------------------------------------------------------------- start an inner solve
-            if (f_start) {
-                f_start = false;
-                { const dbl2 y_ = *Ly; *Ly = dbl2{clampd(y_.x, -1e12, 1e12), clampd(y_.y, -1e12, 1e12)}; }      // y <- Pi_Y(y)
-                lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
-                NMPC_LB_ZERO();
-                // init evaluates u (points 0, 2) and u + h (point 1), h_i = max(1e-6 u_i, 1e-12)
-                const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
-                const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
-                pk_norm_h = sqrt(group_sum<P>(ina ? fma(h1, h1, h2 * h2) : 0.0, lane));
-                xv = h == 1 ? (in ? uv + h1 : 0.0) : uv;
-                xw = h == 1 ? (in ? uw + h2 : 0.0) : uw;
-                yqv = uv; yqw = uw;
-                need_grad = true; state = D_INIT;
+            // (back-off, return of the inner solver, start of an inner solve: rare, behind one test)
+            if (fl & (f_back.bit | f_done.bit | f_start.bit)) {
+                if (f_back) {
+                    f_back = false;
+                    lip_it++;
+                    xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+                }
+                // ---------------------------------------------------------------- the inner solver returned
+                if (f_done) {
+                    f_done = false;
+                    inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
+                                             : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
+                    inner_total += num_iter;
+                    pk_last_cost = cost;                                     // (pk_last_fpr: the norm of the last step started)
+                    uv = hv; uw = hw;                                        // PANOC returns the feasible half step
+                    const bool fin = __builtin_isfinite(uv) && __builtin_isfinite(uw) && __builtin_isfinite(cost) && __builtin_isfinite(pk_last_fpr);
+                    if (__any(in && !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
+                    else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
+                }
+                // ---------------------------------------------------------------- start an inner solve
+                if (f_start) {
+                    f_start = false;
+                    { const dbl2 y_ = *Ly; *Ly = dbl2{clampd(y_.x, -1e12, 1e12), clampd(y_.y, -1e12, 1e12)}; }      // y <- Pi_Y(y)
+                    lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                    NMPC_LB_ZERO();
+                    // init evaluates u (points 0, 2) and u + h (point 1), h_i = max(1e-6 u_i, 1e-12)
+                    const double h1 = EPSILON_LIPSCHITZ * uv > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv : DELTA_LIPSCHITZ;
+                    const double h2 = EPSILON_LIPSCHITZ * uw > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw : DELTA_LIPSCHITZ;
+                    pk_norm_h = sqrt(group_sum<P>(ina ? fma(h1, h1, h2 * h2) : 0.0, lane));
+                    xv = h == 1 ? (in ? uv + h1 : 0.0) : uv;
+                    xw = h == 1 ? (in ? uw + h2 : 0.0) : uw;
+                    yqv = uv; yqw = uw;
+                    need_grad = true; state = D_INIT;
+                }
             }
             if (!running) break;
 
@@ -914,7 +925,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                             NMPC_FETCH_GRAD(src0, gv, gw);
                             NMPC_HALF_STEP(uv, uw);
                             fbe_ok = false;
-                            f_end = true;
+                            NMPC_END_ITERATION();
                         } else {
                             dv = rv; dw = rw;                            // empty buffer: d = r
                             rhs_ls = NMPC_FBE(uv, uw) - pk_sigma * nr2;
@@ -1017,7 +1028,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                         }
                         if (rejected) f_trials = true;
                         else if (exhausted) f_fb = true;
-                        else { uv = pv; uw = pw; pk_fbe_u = lhs; fbe_ok = true; f_end = true; }
+                        else { uv = pv; uw = pw; pk_fbe_u = lhs; fbe_ok = true; NMPC_END_ITERATION(); }
                     }
                 }
             } else if (state == D_LS) {
@@ -1027,7 +1038,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 if (rejected) NMPC_TAKE_TRIAL(psiC, src2);
                 if (rejected) f_trials = true;
                 else if (exhausted) f_fb = true;
-                else { uv = pv; uw = pw; pk_fbe_u = lhs; fbe_ok = true; f_end = true; }
+                else { uv = pv; uw = pw; pk_fbe_u = lhs; fbe_ok = true; NMPC_END_ITERATION(); }
             } else if (state == D_FB) {
                 // psi, grad psi at u_bar: the plain forward-backward step (as in iteration 0)
                 n_grad++;
@@ -1036,7 +1047,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
                 NMPC_FETCH_GRAD(src0, gv, gw);
                 NMPC_HALF_STEP(uv, uw);
                 fbe_ok = false;
-                f_end = true;
+                NMPC_END_ITERATION();
             } else {    // D_ALM: F1, F2 at the inner solution
                 n_cost++;
                 const double tv = fma(yv, cbar_inv, eav), tw = fma(yw, cbar_inv, eaw);
@@ -1296,6 +1307,7 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 2) void nmpc_solve_hyb_kernel(KArg
 #undef NMPC_GRAM_BWD
 #undef NMPC_GRAM_BOTH
 #undef NMPC_TAKE_TRIAL
+#undef NMPC_END_ITERATION
 #undef NMPC_HALF_STEP
 #undef NMPC_FBE
 
