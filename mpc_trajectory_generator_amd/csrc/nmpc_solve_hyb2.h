@@ -592,6 +592,50 @@ __global__ __launch_bounds__(64) void nmpc_eval2_kernel(KArgs a)
 // ---------------------------------------------------------------------------------------------
 // the solver: nmpc_solve_hyb.h's state machine on two-stage vectors
 // ---------------------------------------------------------------------------------------------
+// the pipelined recurrence steps of nmpc_solve_hyb.h for two stages per lane (gram_fwd_step / gram_bwd_step there have the account)
+template <int J>
+__device__ __forceinline__ double gram2_fwd_step(double &ga1, double &ga2, double &dva, double &dvb, double &dwa, double &dwb, double rho, double gs,
+                                                 double gy, double alp, double y1a, double y1b, double y2a, double y2b)
+{
+    double al;
+    asm("v_mul_f64 %0, %7, %1\n\t"
+        "v_fmac_f64_dpp %3, -%10, %11 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, -%10, %12 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, -%10, %13 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, -%10, %14 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, -%0, %8 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, -%0, %9 row_newbcast:%15 row_mask:0xf bank_mask:0xf"
+        : "=&v"(al), "+v"(ga1), "+v"(ga2), "+v"(dva), "+v"(dvb), "+v"(dwa), "+v"(dwb)
+        : "v"(rho), "v"(gs), "v"(gy), "v"(alp), "v"(y1a), "v"(y1b), "v"(y2a), "v"(y2b), "n"(J), "n"(J - 1));
+    return al;
+}
+template <int J>
+__device__ __forceinline__ double gram2_bwd_step(double &ga2, double &dva, double &dvb, double &dwa, double &dwb, double rho, double alv, double gr,
+                                                 double abp, double s1a, double s1b, double s2a, double s2b)
+{
+    double ab;
+    asm("v_mul_f64 %0, %6, %1\n\t"
+        "v_add_f64 %0, %7, -%0\n\t"
+        "v_fmac_f64_dpp %2, %9, %10 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %9, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %9, %12 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %9, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %0, %8 row_newbcast:%14 row_mask:0xf bank_mask:0xf"
+        : "=&v"(ab), "+v"(ga2), "+v"(dva), "+v"(dvb), "+v"(dwa), "+v"(dwb)
+        : "v"(rho), "v"(alv), "v"(gr), "v"(abp), "v"(s1a), "v"(s1b), "v"(s2a), "v"(s2b), "n"(J), "n"(J + 1));
+    return ab;
+}
+template <int J>
+__device__ __forceinline__ void fnma4_row_bcast(double &a1, double &a2, double &a3, double &a4, double x, double y1, double y2, double y3, double y4,
+                                                double after)
+{
+    asm("v_fmac_f64_dpp %0, -%4, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, -%4, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, -%4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, -%4, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+        : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "v"(x), "v"(y1), "v"(y2), "v"(y3), "v"(y4), "v"(after), "n"(J));
+}
+
 // forward-backward envelope at the point whose cost / gradient step / half step / gradient are given (state layout)
 __device__ __forceinline__ double fbe_value2(double cost, double gamma, double hig, D2 sv, D2 sw, D2 hv, D2 hw, D2 gv, D2 gw, int lane)
 {
@@ -747,20 +791,30 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
 #endif
 
         for (;;) {
-            // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
             bool lb_batch = false;                     // this pass starts with the batch of inner products (f_back, f_begin)
-            if (f_back) {
-                if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }
-                lb_active = 0; lb_first = true;
-                NMPC2_LB_ZERO();
-                fbe_ok = false;
-                Lc *= 2.0; gamma /= 2.0;
-                sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-                c_lip = GAMMA_L_COEFF / (2.0 * gamma);
-                Lpar[19] = 0.5 / gamma;      // (the envelope's factor; helpers read it with the request)
-                NMPC2_HALF_STEP(uv, uw);
-                rv = uv - hv; rw = uw - hw;
-                lb_batch = true;
+            // (the two rare phases behind ONE test: nmpc_solve_hyb.h)
+            if (fl & (f_back.bit | f_fb.bit)) {
+                // ---------------------------------------------------------------- backtrack: L <- 2L, gamma <- gamma/2
+                if (f_back) {
+                    if (posted) { posted = false; if (lane == 0) ctl_store(ctl + CTL_CLAIM + wid, 0); }
+                    lb_active = 0; lb_first = true;
+                    NMPC2_LB_ZERO();
+                    fbe_ok = false;
+                    Lc *= 2.0; gamma /= 2.0;
+                    sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+                    c_lip = GAMMA_L_COEFF / (2.0 * gamma);
+                    Lpar[19] = 0.5 / gamma;      // (the envelope's factor; helpers read it with the request)
+                    NMPC2_HALF_STEP(uv, uw);
+                    lb_batch = true;
+                }
+                // ---------------------------------------------------------------- every trial failed (opts.ls_failure = 1)
+                if (f_fb) {
+                    f_fb = false;
+                    tau = 0.0;
+                    ld4<H2_COLS>(Cgk, tc, gv, gw);
+                    NMPC2_HALF_STEP(uv, uw);
+                    xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
+                }
             }
             // ---------------------------------------------------------------- line-search trials (tau, ls_n) | (tau/2, ls_n+1) | (tau/4, ls_n+2)
             if (f_trials) {
@@ -773,15 +827,9 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 yqw = fma2(-t4_, dw, fma2(-om4_, rw, uw));
                 need_grad = true; state = D_LS;
             }
-            // ---------------------------------------------------------------- every trial failed (opts.ls_failure = 1)
-            if (f_fb) {
-                f_fb = false;
-                tau = 0.0;
-                ld4<H2_COLS>(Cgk, tc, gv, gw);
-                NMPC2_HALF_STEP(uv, uw);
-                xv = yqv = hv; xw = yqw = hw; need_grad = true; state = D_FB;
-            }
             // ---------------------------------------------------------------- an iteration finished
+            // (Measured, round 6: handled where it is raised, as in nmpc_solve_hyb.h, this kernel is 3 % SLOWER -- 125.1 against 121.1 ms on
+            // cfg 2, with 226 spilled scalars instead of 197 --, although each of the round's three state-machine changes alone is worth 0.3 .. 1.3 %.)
             if (f_end) {
                 f_end = false;
                 iteration++;
@@ -793,12 +841,13 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 }
             }
             // ---------------------------------------------------------------- start of a PANOC step
-            if (f_begin) { rv = uv - hv; rw = uw - hw; lb_batch = true; }
+            if (f_begin) lb_batch = true;
             // ---- the batch of inner products of this step (Gram-form L-BFGS: nmpc_solve_hyb.h has the design; here a quarter is ten stages --
             // five entries of two planes -- and the oracle's qdot runs over 40 stages)
             double gU = 0.0;
             D2 gs1 = d2s(0.0), gs2 = d2s(0.0), gy1 = d2s(0.0), gy2 = d2s(0.0);
             if (lb_batch) {
+                rv = uv - hv; rw = uw - hw;                // the residual of the step (a back-off has just halved gamma and renewed the half step)
                 if (f_begin && iteration >= 1 && !lb_first) {
                     D2 o1, o2, g1, g2;
                     ld4<H2_COLS>(Cos, tc, o1, o2);
@@ -834,11 +883,6 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                 nr2 = lane_scalar(gU, 11);                       // <r, r>
                 gr = lane_scalar(gU, 32 + 11);                   // <g, r>
                 norm_r = sqrt(nr2);
-            }
-            if (f_back) {
-                f_back = false;
-                lip_it++;
-                xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
             }
             if (f_begin) {
                 f_begin = false;
@@ -908,37 +952,42 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         double ga1 = lane_get(gU, 16 + pk_), ga2 = lane_get(gU, 48 + pk_);      // <s_k, r>, <y_k, r>
                         if (took && c16 == 0) { ga1 = lane_scalar(gU, 12); ga2 = lane_scalar(gU, 32 + 12); }
                         const double rho_k = Lrho[pk_];
-// (nmpc_solve_hyb.h: the twenty steps once per head position H of the ring -- every LDS address a per-lane base plus an immediate)
-#define NMPC2_GRAM_FWD(H, J)                                                                       \
-                        do {                                                                       \
-                            constexpr int pj_ = ((H) + (J)) % MAXMEM;                              \
-                            const double gs_ = Lgsy[pkrow + pj_], gy_ = Lgyy[pkrow + pj_];         \
-                            D2 y1_, y2_;                                                           \
-                            ld4<H2_NS>(LY + 2 * H2_NS * (pj_), tt, y1_, y2_);                      \
-                            const double al_ = rho_k * ga1;                                        \
-                            ga1 = fnma_row_bcast<(J)>(ga1, al_, gs_);                              \
-                            fnma5_row_bcast<(J)>(ga2, dv.a, dv.b, dw.a, dw.b, al_, gy_, y1_.a, y1_.b, y2_.a, y2_.b, ga1); \
-                        } while (0)
-#define NMPC2_GRAM_BWD(H, J)                                                                       \
-                        do {                                                                       \
-                            constexpr int pj_ = ((H) + (J)) % MAXMEM;                              \
-                            const double gr_ = Lgsy[pj_ * GRAM_LD + pk_];                           \
-                            D2 s1_, s2_;                                                           \
-                            ld4<H2_NS>(LS + 2 * H2_NS * (pj_), tt, s1_, s2_);                      \
-                            const double be_ = rho_k * ga2;                                        \
-                            const double ab_ = alv - be_;                                          \
-                            ga2 = fma_row_bcast<(J)>(ga2, ab_, gr_);                               \
-                            fma4_row_bcast<(J)>(dv.a, dv.b, dw.a, dw.b, ab_, s1_.a, s1_.b, s2_.a, s2_.b, ga2); \
-                        } while (0)
+// (nmpc_solve_hyb.h: the twenty steps once per head position H of the ring -- every LDS address a per-lane base plus an immediate -- and
+// software-pipelined: the direction updates of the step before fill the two wait states between a coefficient and its DPP read)
+#define NMPC2_GRAM_LDF(H, J)                                                                       \
+                            constexpr int fp##J = ((H) + (J)) % MAXMEM;                            \
+                            const double fgs##J = Lgsy[pkrow + fp##J], fgy##J = Lgyy[pkrow + fp##J]; \
+                            D2 fy1##J, fy2##J;                                                     \
+                            ld4<H2_NS>(LY + 2 * H2_NS * (fp##J), tt, fy1##J, fy2##J)
+#define NMPC2_GRAM_FWD(H, J, JP)                                                                   \
+                            NMPC2_GRAM_LDF(H, J);                                                  \
+                            const double fal##J = gram2_fwd_step<(J)>(ga1, ga2, dv.a, dv.b, dw.a, dw.b, rho_k, fgs##J, fgy##J, fal##JP, fy1##JP.a, fy1##JP.b, fy2##JP.a, fy2##JP.b)
+#define NMPC2_GRAM_LDB(H, J)                                                                       \
+                            constexpr int bp##J = ((H) + (J)) % MAXMEM;                            \
+                            const double bgr##J = Lgsy[bp##J * GRAM_LD + pk_];                     \
+                            D2 bs1##J, bs2##J;                                                     \
+                            ld4<H2_NS>(LS + 2 * H2_NS * (bp##J), tt, bs1##J, bs2##J)
+#define NMPC2_GRAM_BWD(H, J, JP)                                                                   \
+                            NMPC2_GRAM_LDB(H, J);                                                  \
+                            const double bab##J = gram2_bwd_step<(J)>(ga2, dv.a, dv.b, dw.a, dw.b, rho_k, alv, bgr##J, bab##JP, bs1##JP.a, bs1##JP.b, bs2##JP.a, bs2##JP.b)
 #define NMPC2_GRAM_BOTH(H)                                                                                                                \
                         do {                                                                                                              \
-                            NMPC2_GRAM_FWD(H, 0); NMPC2_GRAM_FWD(H, 1); NMPC2_GRAM_FWD(H, 2); NMPC2_GRAM_FWD(H, 3); NMPC2_GRAM_FWD(H, 4);  \
-                            NMPC2_GRAM_FWD(H, 5); NMPC2_GRAM_FWD(H, 6); NMPC2_GRAM_FWD(H, 7); NMPC2_GRAM_FWD(H, 8); NMPC2_GRAM_FWD(H, 9);  \
+                            NMPC2_GRAM_LDF(H, 0);                                                                                         \
+                            const double fal0 = gram_fwd_first(ga1, ga2, rho_k, fgs0, fgy0);                                              \
+                            NMPC2_GRAM_FWD(H, 1, 0); NMPC2_GRAM_FWD(H, 2, 1); NMPC2_GRAM_FWD(H, 3, 2); NMPC2_GRAM_FWD(H, 4, 3);          \
+                            NMPC2_GRAM_FWD(H, 5, 4); NMPC2_GRAM_FWD(H, 6, 5); NMPC2_GRAM_FWD(H, 7, 6); NMPC2_GRAM_FWD(H, 8, 7);          \
+                            NMPC2_GRAM_FWD(H, 9, 8);                                                                                      \
+                            fnma4_row_bcast<9>(dv.a, dv.b, dw.a, dw.b, fal9, fy19.a, fy19.b, fy29.a, fy29.b, ga1);                        \
                             const double alv = rho_k * ga1;                                                                               \
                             ga2 = n_H0 * ga2;                                                                                             \
                             dv = n_H0 * dv; dw = n_H0 * dw;                                                                               \
-                            NMPC2_GRAM_BWD(H, 9); NMPC2_GRAM_BWD(H, 8); NMPC2_GRAM_BWD(H, 7); NMPC2_GRAM_BWD(H, 6); NMPC2_GRAM_BWD(H, 5);  \
-                            NMPC2_GRAM_BWD(H, 4); NMPC2_GRAM_BWD(H, 3); NMPC2_GRAM_BWD(H, 2); NMPC2_GRAM_BWD(H, 1); NMPC2_GRAM_BWD(H, 0);  \
+                            NMPC2_GRAM_LDB(H, 9);                                                                                         \
+                            const double bab9 = alv - rho_k * ga2;                                                                        \
+                            ga2 = fma_row_bcast<9>(ga2, bab9, bgr9);                                                                      \
+                            NMPC2_GRAM_BWD(H, 8, 9); NMPC2_GRAM_BWD(H, 7, 8); NMPC2_GRAM_BWD(H, 6, 7); NMPC2_GRAM_BWD(H, 5, 6);          \
+                            NMPC2_GRAM_BWD(H, 4, 5); NMPC2_GRAM_BWD(H, 3, 4); NMPC2_GRAM_BWD(H, 2, 3); NMPC2_GRAM_BWD(H, 1, 2);          \
+                            NMPC2_GRAM_BWD(H, 0, 1);                                                                                      \
+                            fma4_row_bcast<0>(dv.a, dv.b, dw.a, dw.b, bab0, bs10.a, bs10.b, bs20.a, bs20.b, ga2);                         \
                         } while (0)
                         switch (n_head) {
                         case 0: NMPC2_GRAM_BOTH(0); break;
@@ -953,6 +1002,8 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                         default: NMPC2_GRAM_BOTH(9); break;
                         }
 #undef NMPC2_GRAM_FWD
+#undef NMPC2_GRAM_LDF
+#undef NMPC2_GRAM_LDB
 #undef NMPC2_GRAM_BWD
 #undef NMPC2_GRAM_BOTH
                     }
@@ -980,34 +1031,42 @@ __global__ __launch_bounds__(64 * TEAM_WAVES, 1) void nmpc_solve_hyb2_kernel(KAr
                     }
                 }
             }
-            // ---------------------------------------------------------------- the inner solver returned
-            if (f_done) {
-                f_done = false;
-                inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
-                                         : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
-                inner_total += num_iter;
-                last_fpr = norm_r; last_cost = cost;
-                uv = hv; uw = hw;                                        // PANOC returns the feasible half step
-                const bool fin = __builtin_isfinite(uv.a) && __builtin_isfinite(uw.a) && __builtin_isfinite(uv.b) && __builtin_isfinite(uw.b) &&
-                                 __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
-                if (__any(in & !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
-                else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
-            }
-            // ---------------------------------------------------------------- start an inner solve
-            if (f_start) {
-                f_start = false;
-                { D2 y1, y2; ld4<H2_COLS>(Cy, te, y1, y2); st4<H2_COLS>(Cy, te, clamp2(y1, -1e12, 1e12), clamp2(y2, -1e12, 1e12)); }      // y <- Pi_Y(y)
-                lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
-                NMPC2_LB_ZERO();
-                const D2 h1 = D2{EPSILON_LIPSCHITZ * uv.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.a : DELTA_LIPSCHITZ,
-                                 EPSILON_LIPSCHITZ * uv.b > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.b : DELTA_LIPSCHITZ};
-                const D2 h2 = D2{EPSILON_LIPSCHITZ * uw.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw.a : DELTA_LIPSCHITZ,
-                                 EPSILON_LIPSCHITZ * uw.b > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw.b : DELTA_LIPSCHITZ};
-                norm_h = sqrt(group_sum<P>((ina ? fma(h1.a, h1.a, h2.a * h2.a) : 0.0) + (inb ? fma(h1.b, h1.b, h2.b * h2.b) : 0.0), lane));
-                xv = h == 1 ? D2{ina ? uv.a + h1.a : 0.0, inb ? uv.b + h1.b : 0.0} : uv;
-                xw = h == 1 ? D2{ina ? uw.a + h2.a : 0.0, inb ? uw.b + h2.b : 0.0} : uw;
-                yqv = uv; yqw = uw;
-                need_grad = true; state = D_INIT;
+            // (back-off, return of the inner solver, start of an inner solve: rare, behind one test)
+            if (fl & (f_back.bit | f_done.bit | f_start.bit)) {
+                if (f_back) {
+                    f_back = false;
+                    lip_it++;
+                    xv = yqv = hv; xw = yqw = hw; need_grad = iteration == 0; state = D_LIP;
+                }
+                // ---------------------------------------------------------------- the inner solver returned
+                if (f_done) {
+                    f_done = false;
+                    inner_status = timed_out ? NMPC_NOT_CONVERGED_OUT_OF_TIME
+                                             : (num_iter < max_inner ? NMPC_CONVERGED : NMPC_NOT_CONVERGED_ITERATIONS);
+                    inner_total += num_iter;
+                    last_fpr = norm_r; last_cost = cost;
+                    uv = hv; uw = hw;                                        // PANOC returns the feasible half step
+                    const bool fin = __builtin_isfinite(uv.a) && __builtin_isfinite(uw.a) && __builtin_isfinite(uv.b) && __builtin_isfinite(uw.b) &&
+                                     __builtin_isfinite(cost) && __builtin_isfinite(norm_r);
+                    if (__any(in & !fin)) { final_status = NMPC_NOT_CONVERGED_NOT_FINITE; running = false; }
+                    else { xv = yqv = uv; xw = yqw = uw; need_grad = false; state = D_ALM; }
+                }
+                // ---------------------------------------------------------------- start an inner solve
+                if (f_start) {
+                    f_start = false;
+                    { D2 y1, y2; ld4<H2_COLS>(Cy, te, y1, y2); st4<H2_COLS>(Cy, te, clamp2(y1, -1e12, 1e12), clamp2(y2, -1e12, 1e12)); }      // y <- Pi_Y(y)
+                    lb_active = 0; lb_first = true; iteration = 0; num_iter = 0; tau = 1.0;
+                    NMPC2_LB_ZERO();
+                    const D2 h1 = D2{EPSILON_LIPSCHITZ * uv.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.a : DELTA_LIPSCHITZ,
+                                     EPSILON_LIPSCHITZ * uv.b > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uv.b : DELTA_LIPSCHITZ};
+                    const D2 h2 = D2{EPSILON_LIPSCHITZ * uw.a > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw.a : DELTA_LIPSCHITZ,
+                                     EPSILON_LIPSCHITZ * uw.b > DELTA_LIPSCHITZ ? EPSILON_LIPSCHITZ * uw.b : DELTA_LIPSCHITZ};
+                    norm_h = sqrt(group_sum<P>((ina ? fma(h1.a, h1.a, h2.a * h2.a) : 0.0) + (inb ? fma(h1.b, h1.b, h2.b * h2.b) : 0.0), lane));
+                    xv = h == 1 ? D2{ina ? uv.a + h1.a : 0.0, inb ? uv.b + h1.b : 0.0} : uv;
+                    xw = h == 1 ? D2{ina ? uw.a + h2.a : 0.0, inb ? uw.b + h2.b : 0.0} : uw;
+                    yqv = uv; yqw = uw;
+                    need_grad = true; state = D_INIT;
+                }
             }
             if (!running) break;
 
