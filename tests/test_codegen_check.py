@@ -70,3 +70,29 @@ def test_dpp_hazard_check_counts_wait_states():
 """
     n, bad = cc.check_dpp_hazards(asm)
     assert n == 4 and [b[1].split()[0] for b in bad] == ["v_mov_b32_dpp", "v_fmac_f64_dpp"] and "v6" in bad[0][1]
+
+
+def test_dpp_hazard_check_on_the_pipelined_recurrence_step():
+    """The software-pipelined Gram recurrences (nmpc_solve_hyb.h, gram_fwd_step / gram_bwd_step) carry no s_nop: the direction updates of the step
+    before fill the two wait states between a coefficient's multiply (add) and its DPP read.  The shape as written passes; with one filler
+    missing it is flagged."""
+    fwd = """_Z3foov:
+\tv_mul_f64 v[20:21], v[30:31], v[2:3]
+\tv_fmac_f64_dpp v[6:7], -v[22:23], v[40:41] row_newbcast:2 row_mask:0xf bank_mask:0xf
+\tv_fmac_f64_dpp v[8:9], -v[22:23], v[42:43] row_newbcast:2 row_mask:0xf bank_mask:0xf
+\tv_fmac_f64_dpp v[2:3], -v[20:21], v[44:45] row_newbcast:3 row_mask:0xf bank_mask:0xf
+\tv_fmac_f64_dpp v[4:5], -v[20:21], v[46:47] row_newbcast:3 row_mask:0xf bank_mask:0xf
+.Lfunc_end0:
+"""
+    n, bad = cc.check_dpp_hazards(fwd)
+    assert n == 4 and not bad
+    bwd_short = """_Z3barv:
+\tv_mul_f64 v[20:21], v[30:31], v[4:5]
+\tv_add_f64 v[20:21], v[32:33], -v[20:21]
+\tv_fmac_f64_dpp v[6:7], v[22:23], v[40:41] row_newbcast:4 row_mask:0xf bank_mask:0xf
+\tv_fmac_f64_dpp v[4:5], v[20:21], v[44:45] row_newbcast:3 row_mask:0xf bank_mask:0xf
+.Lfunc_end1:
+"""
+    n, bad = cc.check_dpp_hazards(bwd_short)
+    assert n == 2 and len(bad) == 1 and "v[20:21]" in bad[0][1]
+
